@@ -1,0 +1,189 @@
+/* include/stark_mlwe.h — C-ABI of libstark_mlwe_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the proving hot path of saholmes/stark-mlwe.  The reference has no FFI
+ * seam of its own (100 % safe Rust); these entry points sit BENEATH the Rust signatures listed in
+ * SURVEY.md §8(b), which stay unchanged.  Each declaration cites the reference item it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the Rust `extern "C"` block and
+ * the wrappers a maintainer adds.
+ *
+ * Conventions
+ *   - A field element is 4 little-endian uint64_t limbs in Montgomery form (R = 2^256): exactly the
+ *     in-memory layout of ark-ff `Fp<MontBackend<_,4>,4>`, so `&[F]` <-> `const uint64_t*` is zero-copy.
+ *   - Plain-named functions take HOST pointers (what a Rust slice hands over) and return when the
+ *     result is in the caller's buffer.  `*_dev` variants take DEVICE pointers obtained from
+ *     stark_malloc (or any hipMalloc'd / torch CUDA memory) and are stream-ordered on the context's
+ *     stream; call stark_ctx_sync before reading results on the host.
+ *   - Every function returns a status: 0 = OK, negative = error class.  stark_last_error() gives text.
+ *     The Rust wrappers turn non-zero into panic!, matching the reference's assert!/panic! behaviour
+ *     (fri.rs:86-87, merkle/src/lib.rs:148,161).
+ *   - One context may be used by one host thread at a time; distinct contexts are independent.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     STARK_ERR_HIP.
+ */
+#ifndef STARK_MLWE_H
+#define STARK_MLWE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STARK_OK               0
+#define STARK_ERR_INVALID_ARG (-1)
+#define STARK_ERR_HIP         (-2)
+#define STARK_ERR_RCCL        (-3)
+#define STARK_ERR_OOM         (-4)
+#define STARK_ERR_UNSUPPORTED (-5)
+
+#define STARK_FIELD_PALLAS_FR    0   /* crates/field/src/lib.rs:13  (the prover field)        */
+#define STARK_FIELD_BLS12_381_FR 1   /* crates/fft/src/lib.rs:1     (the `fft` crate's field) */
+
+typedef struct stark_ctx stark_ctx_t;
+typedef struct stark_params stark_params_t;
+typedef struct stark_tree stark_tree_t;
+typedef struct stark_fri_state stark_fri_state_t;
+typedef struct stark_proof stark_proof_t;
+
+/* ---- context / memory ------------------------------------------------------------------------- */
+int32_t stark_version(void);
+/* device: HIP device ordinal.  stream: a hipStream_t to run on (e.g. torch's current stream), or NULL
+ * to let the context create its own. */
+int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out);
+int32_t stark_ctx_destroy(stark_ctx_t* ctx);
+int32_t stark_ctx_sync(stark_ctx_t* ctx);
+const char* stark_last_error(stark_ctx_t* ctx);
+int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr);
+int32_t stark_free(stark_ctx_t* ctx, void* dptr);
+int32_t stark_memcpy_h2d(stark_ctx_t* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int32_t stark_memcpy_d2h(stark_ctx_t* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* HIP-event timing on the context's stream (bench.py measures kernels with these). */
+int32_t stark_timer_start(stark_ctx_t* ctx);
+int32_t stark_timer_stop_ms(stark_ctx_t* ctx, float* ms);
+
+/* ---- Poseidon constants -------------------------------------------------------------------------
+ * PoseidonParams / PoseidonParamsDynamic (poseidon/src/lib.rs:16-21, 104-114).  Constants are passed
+ * in as the Rust side derived them (row-major mds[i][j], rc_full[r][i], rc_partial[r]); the library
+ * turns them into kernel form (LU factors, sparse partial-round matrices).  t in {9,17,33,65,129}. */
+int32_t stark_poseidon_params_upload(stark_ctx_t* ctx, int32_t t, int32_t rf, int32_t rp, const uint64_t* mds,
+                                     const uint64_t* rc_full, const uint64_t* rc_partial, stark_params_t** out);
+/* Same derivations done inside the library (BLAKE3, utils/src/lib.rs:16-22):
+ *   for_width:  poseidon_params_for_width(t)                        poseidon/src/lib.rs:120-146
+ *   t17_seed :  params::generate_params_t17_x5(seed)                poseidon/src/lib.rs:318-356
+ *               (seed "POSEIDON-T17-X5-TRANSCRIPT" = transcript::default_params, transcript/src/lib.rs:44-46) */
+int32_t stark_poseidon_params_for_width(stark_ctx_t* ctx, int32_t t, stark_params_t** out);
+int32_t stark_poseidon_params_t17_seed(stark_ctx_t* ctx, const uint8_t* seed, size_t seed_len, stark_params_t** out);
+int32_t stark_poseidon_params_export(stark_params_t* p, int32_t* t, int32_t* rf, int32_t* rp, uint64_t* mds, uint64_t* rc_full, uint64_t* rc_partial);
+int32_t stark_poseidon_params_free(stark_params_t* p);
+
+/* ---- Poseidon ------------------------------------------------------------------------------------ */
+/* permute / permute_dynamic (poseidon/src/lib.rs:31, 219): nstates states of t elements, in place. */
+int32_t stark_poseidon_permute_batch(stark_ctx_t* ctx, stark_params_t* p, uint64_t* states, size_t nstates);
+int32_t stark_poseidon_permute_batch_dev(stark_ctx_t* ctx, stark_params_t* p, uint64_t* states, size_t nstates);
+/* hash_with_ds_dynamic (poseidon/src/lib.rs:288-312) over a batch: hash k absorbs
+ * ds_fields[k*nds .. +nds] then inputs[k*cnt .. +cnt], pad 1||0*, squeezes state[0]. */
+int32_t stark_poseidon_hash_with_ds_dynamic(stark_ctx_t* ctx, stark_params_t* p, const uint64_t* ds_fields, size_t nds,
+                                            const uint64_t* inputs, size_t cnt, size_t n, uint64_t* out);
+/* hash_with_ds (legacy, poseidon/src/lib.rs:85-100): t = 17, ds_tag in the capacity lane, no padding. */
+int32_t stark_poseidon_hash_with_ds(stark_ctx_t* ctx, stark_params_t* p, const uint64_t* inputs, size_t cnt, const uint64_t* ds_tag, uint64_t* out);
+/* One Merkle level: out[k] = hash_with_ds_dynamic([arity, level, pos0+k, tree_label], in[k*arity ..])
+ * (merkle/src/lib.rs:167-176); the last chunk may be short. */
+int32_t stark_poseidon_hash_ds_batch(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t tree_label,
+                                     const uint64_t* in, size_t n_in, uint64_t* out);
+int32_t stark_poseidon_hash_ds_batch_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t tree_label,
+                                         const uint64_t* in, size_t n_in, uint64_t* out);
+/* hash_leaf_pair over a layer (fri.rs:38-44 as used at fri.rs:283): h[i] = hash_leaf_pair(f[i], s_i),
+ * s_i = f_next[i / m], or zero when f_next == NULL (fri.rs:266).  tparams = transcript params (t=17). */
+int32_t stark_leaf_pair_hash(stark_ctx_t* ctx, stark_params_t* tparams, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h);
+int32_t stark_leaf_pair_hash_dev(stark_ctx_t* ctx, stark_params_t* tparams, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h);
+/* tr_hash_fields_tagged (fri.rs:28-35): n_hashes independent transcript hashes of k fields each. */
+int32_t stark_tr_hash_fields_tagged(stark_ctx_t* ctx, stark_params_t* tparams, const char* tag, const uint64_t* fields, size_t k, size_t n_hashes, uint64_t* out);
+int32_t stark_tr_hash_fields_tagged_dev(stark_ctx_t* ctx, stark_params_t* tparams, const char* tag, const uint64_t* fields, size_t k, size_t n_hashes, uint64_t* out);
+
+/* ---- Merkle ---------------------------------------------------------------------------------------
+ * MerkleTree::new / new_pairs (merkle/src/lib.rs:147-193, 392-445): level-by-level build, all levels
+ * kept resident on the device (openings read them, :261-291).  pairs != 0 => leaves are (f, cp) pairs
+ * hashed with the leaf DS level 2^32-1 (:380-388).  `first_pos` / `level0` let a shard build its part
+ * of a larger tree (DS positions are global): pass 0 / 0 for a whole tree. */
+int32_t stark_merkle_build(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t tree_label, const uint64_t* leaves, size_t n,
+                           int32_t pairs, const uint64_t* cp, stark_tree_t** out);
+int32_t stark_merkle_build_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t tree_label, const uint64_t* leaves, size_t n,
+                               int32_t pairs, const uint64_t* cp, uint64_t first_pos, uint32_t level0, int32_t stop_at_len, stark_tree_t** out);
+int32_t stark_merkle_num_levels(stark_tree_t* t);
+size_t  stark_merkle_level_len(stark_tree_t* t, int32_t lvl);
+int32_t stark_merkle_root(stark_tree_t* t, uint64_t* out4);
+int32_t stark_merkle_level(stark_tree_t* t, int32_t lvl, uint64_t* out);                         /* host copy of a level */
+const uint64_t* stark_merkle_level_dev(stark_tree_t* t, int32_t lvl);                           /* device pointer     */
+int32_t stark_merkle_gather(stark_tree_t* t, int32_t lvl, const size_t* idx, size_t k, uint64_t* out);
+/* open_union_of_paths (merkle/src/lib.rs:246-315) → canonical MerkleProof encoding (DESIGN.md
+ * "Proof encoding"): call with buf == NULL to get the length. */
+int32_t stark_merkle_open(stark_tree_t* t, const size_t* idx, size_t k, uint8_t* buf, size_t cap, size_t* len);
+int32_t stark_merkle_free(stark_tree_t* t);
+
+/* ---- FRI ------------------------------------------------------------------------------------------ */
+/* fri_sample_z_ell (fri.rs:59-82). */
+int32_t stark_fri_sample_z(stark_ctx_t* ctx, stark_params_t* tparams, uint64_t seed_z, size_t level, size_t domain_size, uint64_t* z4);
+/* fri_fold_layer (fri.rs:85-102): out[b] = sum_{t<m} f[b*m+t] z^t, n % m == 0, m >= 2. */
+int32_t stark_fri_fold(stark_ctx_t* ctx, const uint64_t* f, size_t n, const uint64_t* z4, size_t m, uint64_t* out);
+int32_t stark_fri_fold_dev(stark_ctx_t* ctx, const uint64_t* f, size_t n, const uint64_t* z4, size_t m, uint64_t* out);
+/* fri_build_transcript (fri.rs:231-312): all folds, per-layer leaf hashes and the L+1 trees.
+ * z_l are derived inside (they depend only on (seed_z, l, size), fri.rs:250). */
+int32_t stark_fri_build(stark_ctx_t* ctx, const uint64_t* f0, size_t n0, const size_t* schedule, size_t L, uint64_t seed_z, stark_fri_state_t** out);
+int32_t stark_fri_build_dev(stark_ctx_t* ctx, const uint64_t* f0, size_t n0, const size_t* schedule, size_t L, uint64_t seed_z, stark_fri_state_t** out);
+int32_t stark_fri_num_layers(stark_fri_state_t* s);                 /* L + 1 */
+size_t  stark_fri_layer_len(stark_fri_state_t* s, int32_t layer);
+int32_t stark_fri_layer_f(stark_fri_state_t* s, int32_t layer, uint64_t* out);
+int32_t stark_fri_layer_root(stark_fri_state_t* s, int32_t layer, uint64_t* out4);
+int32_t stark_fri_layer_z(stark_fri_state_t* s, int32_t layer, uint64_t* out4);
+stark_tree_t* stark_fri_layer_tree(stark_fri_state_t* s, int32_t layer);
+int32_t stark_fri_state_free(stark_fri_state_t* s);
+
+/* ---- DEEP-ALI (next row N1) ---------------------------------------------------------------------- */
+/* deep_ali_merge_evals(_blinded) (deep_ali/src/lib.rs:48-105).  r_opt / beta may be NULL.  c_star may be NULL. */
+int32_t stark_ali_merge(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt,
+                        const uint64_t* beta4, const uint64_t* omega4, const uint64_t* z4, size_t n, uint64_t* f0, uint64_t* c_star4);
+int32_t stark_ali_merge_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt,
+                            const uint64_t* beta4, const uint64_t* omega4, const uint64_t* z4, size_t n, uint64_t* f0, uint64_t* c_star4);
+/* DeepAliRealBuilder::build_f0 (fri.rs:535-569): 4 column sponges, (z, beta) sampling, merge.
+ * aux7 (optional, host): col digests A,S,E,T, seed_f, z, beta. */
+int32_t stark_build_f0(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, size_t n0, uint64_t* f0, uint64_t* aux7);
+int32_t stark_build_f0_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, size_t n0, uint64_t* f0, uint64_t* aux7_host);
+
+/* ---- end-to-end prove (next row N2) -------------------------------------------------------------- */
+/* deep_fri_prove (fri.rs:601-641) with DeepAliRealBuilder::default().  If f0 != NULL the builder is
+ * skipped and a,s,e,t are ignored ("prove given f0").  The proof is returned in the canonical byte
+ * encoding (DESIGN.md "Proof encoding"). */
+int32_t stark_deep_fri_prove(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* f0,
+                             size_t n0, const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out);
+int32_t stark_deep_fri_prove_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* f0,
+                                 size_t n0, const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out);
+size_t  stark_proof_len(stark_proof_t* p);
+int32_t stark_proof_bytes(stark_proof_t* p, uint8_t* out);
+size_t  stark_proof_size_estimate(stark_proof_t* p);                /* deep_fri_proof_size_bytes, fri.rs:764-805 */
+double  stark_proof_stage_ms(stark_proof_t* p, int32_t stage);     /* 0 build_f0, 1 fri_build, 2 queries+encode */
+int32_t stark_proof_free(stark_proof_t* p);
+
+/* ---- NTT (crates/fft/src/lib.rs:6-32) ------------------------------------------------------------- */
+/* fft_in_place / ifft_in_place: natural order in and out; inverse != 0 includes the n^-1 scaling.
+ * coset4 (optional): evaluate on coset4 * <w> (forward) / interpolate from it (inverse). */
+int32_t stark_ntt(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4);
+int32_t stark_ntt_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4);
+/* LDE: 2^log_n evaluations on <w_n> -> 2^(log_n+log_blowup) evaluations on coset4 * <w_N> (coset4 NULL => 1). */
+int32_t stark_lde(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* coset4, uint64_t* out);
+int32_t stark_lde_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* coset4, uint64_t* out);
+/* Building blocks of the multi-GPU six-step NTT (one process per GPU; the exchange between the two
+ * is an all-to-all done by the caller, see stark_mlwe_amd/dist.py):
+ *   phase A: `ncols` column NTTs of size 2^log_rows on a row-major [2^log_rows][ncols] slab, then the
+ *            twiddle w_N^(col_global * k) (N = 2^log_n, col_global = col0 + local column).
+ *   phase B: `nrows` contiguous NTTs of size 2^log_cols (plain stark_ntt batched over rows). */
+int32_t stark_ntt_columns_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, int32_t inverse);
+int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t nrows, size_t log_cols, int32_t inverse, const uint64_t* scale4);
+
+/* ---- synthetic inputs for benchmarks (DESIGN.md "Synthetic inputs") ------------------------------- */
+int32_t stark_synth_column_dev(stark_ctx_t* ctx, uint64_t seed, uint64_t col, size_t i0, size_t n, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARK_MLWE_H */

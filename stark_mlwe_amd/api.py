@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C-ABI.
+
+Same names, argument meaning and error behaviour as the Rust functions in SURVEY.md §8(b)
+(`permute`, `hash_with_ds_dynamic`, `MerkleTree::new/new_pairs`, `fri_fold_layer`, `compute_s_layer`,
+`fri_build_transcript`, `deep_fri_prove`, `fft`/`ifft` …); a failed precondition raises StarkError where
+the reference panics.  Field vectors are numpy uint64 arrays of shape (n, 4): the 4 little-endian
+Montgomery limbs of ark-ff — the same bytes a Rust `&[F]` holds.
+
+Everything here calls libstark_mlwe_hip.so; nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._abi import StarkError, load_library
+
+PALLAS_FR = 0
+BLS12_381_FR = 1
+
+
+def _arr(x, cols=4):
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    if a.ndim == 1 and cols == 4 and a.size == 4:
+        a = a.reshape(1, 4)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Params:
+    """PoseidonParams / PoseidonParamsDynamic handle (poseidon/src/lib.rs:16-21, 104-114)."""
+
+    def __init__(self, ctx, handle, owned=True):
+        self.ctx, self.h, self.owned = ctx, handle, owned
+        t, rf, rp = C.c_int32(), C.c_int32(), C.c_int32()
+        ctx._chk(ctx.lib.stark_poseidon_params_export(handle, C.byref(t), C.byref(rf), C.byref(rp), None, None, None))
+        self.t, self.rounds_full, self.rounds_partial = t.value, rf.value, rp.value
+        self.rate = self.t - 1
+
+    def export(self):
+        mds = np.zeros((self.t * self.t, 4), np.uint64)
+        rcf = np.zeros((self.rounds_full * self.t, 4), np.uint64)
+        rcp = np.zeros((self.rounds_partial, 4), np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_poseidon_params_export(self.h, None, None, None, _ptr(mds), _ptr(rcf), _ptr(rcp)))
+        return mds, rcf, rcp
+
+    def free(self):
+        if self.owned and self.h:
+            self.ctx.lib.stark_poseidon_params_free(self.h)
+            self.h = None
+
+
+class MerkleChannelCfg:
+    """merkle/src/lib.rs:84-112."""
+
+    def __init__(self, arity, params=None, tree_label=0):
+        self.arity, self.params, self.tree_label = arity, params, tree_label
+
+    def with_tree_label(self, label):
+        return MerkleChannelCfg(self.arity, self.params, label)
+
+
+class MerkleTree:
+    """merkle/src/lib.rs:114-128: device-resident levels; `levels` materialises them lazily."""
+
+    def __init__(self, ctx, handle, cfg, owned=True):
+        self.ctx, self.h, self.cfg, self.owned = ctx, handle, cfg, owned
+
+    @property
+    def num_levels(self):
+        return self.ctx.lib.stark_merkle_num_levels(self.h)
+
+    def height(self):
+        return self.num_levels - 1
+
+    def level(self, lvl):
+        n = self.ctx.lib.stark_merkle_level_len(self.h, lvl)
+        out = np.zeros((n, 4), np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_merkle_level(self.h, lvl, _ptr(out)))
+        return out
+
+    @property
+    def levels(self):
+        return [self.level(i) for i in range(self.num_levels)]
+
+    def root(self):
+        out = np.zeros(4, np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_merkle_root(self.h, _ptr(out)))
+        return out
+
+    def gather(self, lvl, idx):
+        ix = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros((len(ix), 4), np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_merkle_gather(self.h, lvl, _ptr(ix), len(ix), _ptr(out)))
+        return out
+
+    def open_many(self, indices):
+        """open_union_of_paths (merkle/src/lib.rs:246-315) -> canonical MerkleProof bytes."""
+        ix = np.ascontiguousarray(indices, dtype=np.uint64)
+        ln = C.c_size_t()
+        self.ctx._chk(self.ctx.lib.stark_merkle_open(self.h, _ptr(ix), len(ix), None, 0, C.byref(ln)))
+        buf = (C.c_uint8 * ln.value)()
+        self.ctx._chk(self.ctx.lib.stark_merkle_open(self.h, _ptr(ix), len(ix), buf, ln.value, C.byref(ln)))
+        return bytes(buf)
+
+    open_many_single = open_many
+
+    def free(self):
+        if self.owned and self.h:
+            self.ctx.lib.stark_merkle_free(self.h)
+            self.h = None
+
+
+class FriProverState:
+    """fri.rs:210-216 (layers stay on the device)."""
+
+    def __init__(self, ctx, handle, schedule):
+        self.ctx, self.h, self.schedule = ctx, handle, list(schedule)
+
+    @property
+    def num_layers(self):
+        return self.ctx.lib.stark_fri_num_layers(self.h)
+
+    def f_layer(self, l):
+        n = self.ctx.lib.stark_fri_layer_len(self.h, l)
+        out = np.zeros((n, 4), np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_f(self.h, l, _ptr(out)))
+        return out
+
+    def root(self, l):
+        out = np.zeros(4, np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_root(self.h, l, _ptr(out)))
+        return out
+
+    def z(self, l):
+        out = np.zeros(4, np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_fri_layer_z(self.h, l, _ptr(out)))
+        return out
+
+    def tree(self, l):
+        return MerkleTree(self.ctx, self.ctx.lib.stark_fri_layer_tree(self.h, l), None, owned=False)
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.stark_fri_state_free(self.h)
+            self.h = None
+
+
+class DeepFriParams:
+    """fri.rs:589."""
+
+    def __init__(self, schedule, r, seed_z):
+        self.schedule, self.r, self.seed_z = list(schedule), r, seed_z
+
+
+class Context:
+    """One context = one GPU = one host thread (include/stark_mlwe.h conventions)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.stark_ctx_create(device, stream, C.byref(h))
+        if rc != 0:
+            raise StarkError(rc, "stark_ctx_create failed: no usable HIP device (the product path has no CPU fallback)")
+        self.h = h
+        self._tparams = None
+        self._mparams = {}
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise StarkError(rc, (self.lib.stark_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            for p in list(self._mparams.values()) + ([self._tparams] if self._tparams else []):
+                p.free()
+            self.lib.stark_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._chk(self.lib.stark_ctx_sync(self.h))
+
+    # ---- constants ------------------------------------------------------------------------------
+    def poseidon_params_for_width(self, t):
+        if t not in self._mparams:
+            h = C.c_void_p()
+            self._chk(self.lib.stark_poseidon_params_for_width(self.h, t, C.byref(h)))
+            self._mparams[t] = Params(self, h)
+        return self._mparams[t]
+
+    def poseidon_params_for_arity(self, arity):
+        t = 9 if arity <= 8 else 17 if arity <= 16 else 33 if arity <= 32 else 65 if arity <= 64 else 129
+        if arity > 128:
+            raise StarkError(-5, "unsupported Merkle arity; max supported = 128")
+        return self.poseidon_params_for_width(t)
+
+    def generate_params_t17_x5(self, seed: bytes):
+        h = C.c_void_p()
+        self._chk(self.lib.stark_poseidon_params_t17_seed(self.h, seed, len(seed), C.byref(h)))
+        return Params(self, h)
+
+    def transcript_params(self):
+        if self._tparams is None:
+            self._tparams = self.generate_params_t17_x5(b"POSEIDON-T17-X5-TRANSCRIPT")
+        return self._tparams
+
+    def params_upload(self, t, rf, rp, mds, rc_full, rc_partial):
+        h = C.c_void_p()
+        self._chk(self.lib.stark_poseidon_params_upload(self.h, t, rf, rp, _ptr(_arr(mds)), _ptr(_arr(rc_full)), _ptr(_arr(rc_partial)), C.byref(h)))
+        return Params(self, h)
+
+    # ---- poseidon -----------------------------------------------------------------------------------
+    def permute(self, states, params):
+        """permute / permute_dynamic over a batch: states (nstates, t, 4) -> same shape."""
+        s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        n = s.size // (params.t * 4)
+        self._chk(self.lib.stark_poseidon_permute_batch(self.h, params.h, _ptr(s), n))
+        return s
+
+    permute_dynamic = permute
+
+    def hash_with_ds_dynamic(self, ds_fields, inputs, params, n=1):
+        ds, inp = _arr(ds_fields), _arr(inputs)
+        nds, cnt = ds.shape[0] // n if ds.size else 0, inp.shape[0] // n if inp.size else 0
+        out = np.zeros((n, 4), np.uint64)
+        self._chk(self.lib.stark_poseidon_hash_with_ds_dynamic(self.h, params.h, _ptr(ds), nds, _ptr(inp), cnt, n, _ptr(out)))
+        return out[0] if n == 1 else out
+
+    def hash_with_ds(self, inputs, ds_tag, params):
+        inp = _arr(inputs)
+        out = np.zeros(4, np.uint64)
+        self._chk(self.lib.stark_poseidon_hash_with_ds(self.h, params.h, _ptr(inp), inp.shape[0] if inp.size else 0, _ptr(_arr(ds_tag)), _ptr(out)))
+        return out
+
+    def hash_ds_level(self, params, arity, level, pos0, tree_label, children):
+        ch = _arr(children)
+        out = np.zeros(((ch.shape[0] + arity - 1) // arity, 4), np.uint64)
+        self._chk(self.lib.stark_poseidon_hash_ds_batch(self.h, params.h, arity, level, pos0, tree_label, _ptr(ch), ch.shape[0], _ptr(out)))
+        return out
+
+    def leaf_pair_hash(self, f, f_next, m):
+        """h[i] = hash_leaf_pair(f[i], f_next[i // m]) (f_next None => s = 0), fri.rs:283."""
+        f = _arr(f)
+        fn = None if f_next is None else _arr(f_next)
+        out = np.zeros((f.shape[0], 4), np.uint64)
+        self._chk(self.lib.stark_leaf_pair_hash(self.h, self.transcript_params().h, _ptr(f), _ptr(fn), f.shape[0], m, _ptr(out)))
+        return out
+
+    def hash_leaf_pair(self, f, s):
+        return self.leaf_pair_hash(_arr(f), _arr(s), 1)[0]
+
+    def tr_hash_fields_tagged(self, tag: bytes, fields, n=1):
+        fl = _arr(fields)
+        k = fl.shape[0] // n if fl.size else 0
+        out = np.zeros((n, 4), np.uint64)
+        self._chk(self.lib.stark_tr_hash_fields_tagged(self.h, None, tag, _ptr(fl), k, n, _ptr(out)))
+        return out[0] if n == 1 else out
+
+    # ---- merkle -------------------------------------------------------------------------------------
+    def merkle_cfg(self, arity, tree_label=0):
+        """MerkleChannelCfg::new(arity).with_tree_label(label)."""
+        return MerkleChannelCfg(arity, self.poseidon_params_for_arity(arity), tree_label)
+
+    def merkle_new(self, leaves, cfg):
+        lv = _arr(leaves)
+        h = C.c_void_p()
+        self._chk(self.lib.stark_merkle_build(self.h, cfg.params.h, cfg.arity, cfg.tree_label, _ptr(lv), lv.shape[0] if lv.size else 0, 0, None, C.byref(h)))
+        return MerkleTree(self, h, cfg)
+
+    def merkle_new_pairs(self, f_vals, cp_vals, cfg):
+        f, cp = _arr(f_vals), _arr(cp_vals)
+        if f.shape != cp.shape:
+            raise StarkError(-1, "f and cp length mismatch")
+        h = C.c_void_p()
+        self._chk(self.lib.stark_merkle_build(self.h, cfg.params.h, cfg.arity, cfg.tree_label, _ptr(f), f.shape[0] if f.size else 0, 1, _ptr(cp), C.byref(h)))
+        return MerkleTree(self, h, cfg)
+
+    # ---- fri ---------------------------------------------------------------------------------------
+    def fri_sample_z_ell(self, seed_z, level, domain_size):
+        out = np.zeros(4, np.uint64)
+        self._chk(self.lib.stark_fri_sample_z(self.h, None, seed_z, level, domain_size, _ptr(out)))
+        return out
+
+    def fri_fold_layer(self, f_l, z_l, m):
+        f = _arr(f_l)
+        n = f.shape[0] if f.size else 0
+        out = np.zeros((n // m if m else 0, 4), np.uint64)
+        self._chk(self.lib.stark_fri_fold(self.h, _ptr(f), n, _ptr(_arr(z_l)), m, _ptr(out)))
+        return out
+
+    def compute_s_layer(self, f_l, z_l, m):
+        """fri.rs:123-143: s[i] = fold(f)[i // m] — a replicated view of the folded layer."""
+        return np.repeat(self.fri_fold_layer(f_l, z_l, m), m, axis=0)
+
+    def fri_build_transcript(self, f0, schedule, seed_z):
+        f = _arr(f0)
+        sch = np.ascontiguousarray(schedule, dtype=np.uint64)
+        h = C.c_void_p()
+        self._chk(self.lib.stark_fri_build(self.h, _ptr(f), f.shape[0], _ptr(sch), len(sch), seed_z, C.byref(h)))
+        return FriProverState(self, h, schedule)
+
+    # ---- deep-ali / prove -----------------------------------------------------------------------------
+    def deep_ali_merge_evals(self, a, s, e, t, omega, z, r_eval=None, beta=None, want_c_star=True):
+        a, s, e, t = _arr(a), _arr(s), _arr(e), _arr(t)
+        n = a.shape[0]
+        f0 = np.zeros((n, 4), np.uint64)
+        cs = np.zeros(4, np.uint64) if want_c_star else None
+        r = None if r_eval is None else _arr(r_eval)
+        b = None if beta is None else _arr(beta)
+        self._chk(self.lib.stark_ali_merge(self.h, _ptr(a), _ptr(s), _ptr(e), _ptr(t), _ptr(r), _ptr(b), _ptr(_arr(omega)), _ptr(_arr(z)), n, _ptr(f0), _ptr(cs)))
+        return f0, _arr(z).reshape(4), cs
+
+    def build_f0(self, a, s, e, t, n0):
+        """DeepAliRealBuilder::default().build_f0 (fri.rs:535-569); returns (f0, aux[7])."""
+        a, s, e, t = _arr(a), _arr(s), _arr(e), _arr(t)
+        f0 = np.zeros((n0, 4), np.uint64)
+        aux = np.zeros((7, 4), np.uint64)
+        self._chk(self.lib.stark_build_f0(self.h, _ptr(a), _ptr(s), _ptr(e), _ptr(t), n0, _ptr(f0), _ptr(aux)))
+        return f0, aux
+
+    def deep_fri_prove(self, a, s, e, t, n0, params: DeepFriParams, f0=None):
+        """deep_fri_prove (fri.rs:601-641) -> (canonical proof bytes, size estimate, stage ms)."""
+        sch = np.ascontiguousarray(params.schedule, dtype=np.uint64)
+        h = C.c_void_p()
+        if f0 is None:
+            a, s, e, t = _arr(a), _arr(s), _arr(e), _arr(t)
+            self._chk(self.lib.stark_deep_fri_prove(self.h, _ptr(a), _ptr(s), _ptr(e), _ptr(t), None, n0, _ptr(sch), len(sch), params.r, params.seed_z, C.byref(h)))
+        else:
+            f = _arr(f0)
+            self._chk(self.lib.stark_deep_fri_prove(self.h, None, None, None, None, _ptr(f), n0, _ptr(sch), len(sch), params.r, params.seed_z, C.byref(h)))
+        try:
+            ln = self.lib.stark_proof_len(h)
+            buf = (C.c_uint8 * ln)()
+            self._chk(self.lib.stark_proof_bytes(h, buf))
+            est = self.lib.stark_proof_size_estimate(h)
+            ms = [self.lib.stark_proof_stage_ms(h, i) for i in range(3)]
+        finally:
+            self.lib.stark_proof_free(h)
+        return bytes(buf), est, ms
+
+    # ---- fft (crates/fft/src/lib.rs:6-32) ------------------------------------------------------------
+    def fft(self, coeffs, field=BLS12_381_FR, coset=None):
+        v = _arr(coeffs).copy()
+        log_n = int(v.shape[0]).bit_length() - 1
+        if (1 << log_n) != v.shape[0]:
+            raise StarkError(-1, "radix-2 domain size must be a power of two")
+        self._chk(self.lib.stark_ntt(self.h, field, _ptr(v), log_n, 0, _ptr(None if coset is None else _arr(coset))))
+        return v
+
+    def ifft(self, evals, field=BLS12_381_FR, coset=None):
+        v = _arr(evals).copy()
+        log_n = int(v.shape[0]).bit_length() - 1
+        if (1 << log_n) != v.shape[0]:
+            raise StarkError(-1, "radix-2 domain size must be a power of two")
+        self._chk(self.lib.stark_ntt(self.h, field, _ptr(v), log_n, 1, _ptr(None if coset is None else _arr(coset))))
+        return v
+
+    fft_in_place, ifft_in_place = fft, ifft
+
+    def lde(self, evals, log_blowup, field=PALLAS_FR, coset=None):
+        v = _arr(evals)
+        log_n = int(v.shape[0]).bit_length() - 1
+        out = np.zeros((v.shape[0] << log_blowup, 4), np.uint64)
+        self._chk(self.lib.stark_lde(self.h, field, _ptr(v), log_n, log_blowup, _ptr(None if coset is None else _arr(coset)), _ptr(out)))
+        return out

@@ -1,0 +1,393 @@
+// stark_mlwe_amd/csrc/capi_core.hip — context, memory, Poseidon constants, Poseidon / Merkle entry points.
+// C-ABI declared in include/stark_mlwe.h.  No CPU compute fallback anywhere in this file: every
+// bulk operation is a kernel launch on the context's stream.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include "ctx.hpp"
+#include "poseidon_dev.hpp"
+#include "fri_dev.hpp"
+
+using namespace stark;
+
+static const size_t kMaxLds = 160 * 1024;
+static inline int poseidon_block(int t) { return (size_t)t * 32 * 64 <= kMaxLds ? 64 : 32; }
+static inline size_t poseidon_lds(int t, int block) { return (size_t)t * 32 * block; }
+
+namespace stark {
+
+int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) { STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        STARK_HIP(ctx, hipMalloc(&ctx->scratch, bytes)); ctx->scratch_bytes = bytes;
+    }
+    *out = ctx->scratch; return STARK_OK;
+}
+
+static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
+    if (host::rp_for_width(P->ref.t) < 0) return ctx->fail(STARK_ERR_UNSUPPORTED, "Poseidon width must be one of 9,17,33,65,129");
+    P->kc = host::make_kernel_consts(P->ref);
+    if (!P->kc.ok) return ctx->fail(STARK_ERR_UNSUPPORTED, "MDS matrix has a singular leading minor: LU/sparse kernel form unavailable");
+    const host::KernelConsts& k = P->kc;
+    std::vector<fr_t> blob; auto put = [&](const std::vector<fr_t>& v) { size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
+    size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds);
+    STARK_HIP(ctx, hipMalloc((void**)&P->blob, blob.size() * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(P->blob, blob.data(), blob.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P->dev.t = k.t; P->dev.rf = k.rf; P->dev.rp = k.rp;
+    P->dev.rc_full = P->blob + o_rcf; P->dev.rc_partial = P->blob + o_rcp; P->dev.lu = P->blob + o_lu; P->dev.lu_pre = P->blob + o_pre;
+    P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds;
+    return STARK_OK;
+}
+static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c, stark_params** out) {
+    stark_params* P = new stark_params(); P->ctx = ctx; P->ref = c;
+    int32_t rc = params_finish(ctx, P);
+    if (rc != STARK_OK) { if (P->blob) (void)hipFree(P->blob); delete P; return rc; }
+    *out = P; return STARK_OK;
+}
+int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out) {
+    if (!ctx->tparams) STARK_TRY(params_from_consts(ctx, host::consts_transcript(), &ctx->tparams));
+    *out = ctx->tparams; return STARK_OK;
+}
+int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out) {
+    auto it = ctx->merkle_params.find(t);
+    if (it == ctx->merkle_params.end()) {
+        if (host::rp_for_width(t) < 0) return ctx->fail(STARK_ERR_UNSUPPORTED, "unsupported Poseidon width");
+        stark_params* P = nullptr; STARK_TRY(params_from_consts(ctx, host::consts_for_width(t), &P));
+        ctx->merkle_params[t] = P; *out = P; return STARK_OK;
+    }
+    *out = it->second; return STARK_OK;
+}
+
+// Transcript framing for `tr_hash_fields_tagged(tag, xs)` (fri.rs:28-35 over transcript/src/lib.rs:55-101):
+// absorbed stream = [AB, w("FRI/FS"), AB, words(tag).., xs.., CH, AB, w("out")], capacity lane = INIT.
+static int32_t tr_frame(stark_ctx* ctx, const char* label, const char* tag, const char* out_label, fr_t** dev, int* np, int* ns) {
+    std::string key = std::string(label) + "\x01" + tag + "\x01" + out_label;
+    auto it = ctx->tr_frames.find(key);
+    if (it == ctx->tr_frames.end()) {
+        std::vector<fr_t> fr; const fr_t AB = host::h_tag("FSv1-ABSORB-BYTES"), CH = host::h_tag("FSv1-CHALLENGE");
+        fr.push_back(AB); for (auto& w : host::h_words(label)) fr.push_back(w);
+        fr.push_back(AB); for (auto& w : host::h_words(tag)) fr.push_back(w);
+        int p = (int)fr.size();
+        fr.push_back(CH); fr.push_back(AB); for (auto& w : host::h_words(out_label)) fr.push_back(w);
+        int s = (int)fr.size() - p;
+        fr_t* d = nullptr; STARK_HIP(ctx, hipMalloc((void**)&d, fr.size() * sizeof(fr_t)));
+        STARK_HIP(ctx, hipMemcpyAsync(d, fr.data(), fr.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+        STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->tr_frames[key] = d; ctx->tr_frame_dims[key] = {p, s};
+        it = ctx->tr_frames.find(key);
+    }
+    *dev = it->second; *np = ctx->tr_frame_dims[key].first; *ns = ctx->tr_frame_dims[key].second; return STARK_OK;
+}
+int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev) {
+    stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
+    fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tag, "out", &frame, &np, &ns));
+    if (n == 0) return STARK_OK;
+    TrJob J; J.prefix = frame; J.np = np; J.suffix = frame + np; J.ns = ns; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.k = k; J.n = n;
+    const int block = 64; const size_t lds = poseidon_lds(17, block);
+    hipLaunchKernelGGL(k_tr_hash, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, ctx->stream, tp->dev, J, fields_dev, out_dev);
+    STARK_HIP(ctx, hipGetLastError());
+    return STARK_OK;
+}
+int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out) {
+    DevBuf in, o; STARK_HIP(ctx, in.alloc(fields.size() * sizeof(fr_t))); STARK_HIP(ctx, o.alloc(sizeof(fr_t)));
+    if (!fields.empty()) STARK_HIP(ctx, hipMemcpyAsync(in.p, fields.data(), fields.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(tr_hash_dev(ctx, tag, in.fr(), fields.size(), 1, o.fr()));
+    STARK_HIP(ctx, hipMemcpyAsync(out, o.p, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+
+}  // namespace stark
+
+// leaf template of hash_leaf_pair (fri.rs:38-44)
+static int32_t ctx_leaf_init(stark_ctx* ctx, fr_t** out) {
+    if (!ctx->leaf_init) {
+        const fr_t AB = host::h_tag("FSv1-ABSORB-BYTES"), CH = host::h_tag("FSv1-CHALLENGE");
+        fr_t init[17]; for (auto& x : init) x = host::h_zero();
+        init[0] = AB; init[1] = host::h_words("FRI/leaf/poseidon")[0]; init[2] = AB; init[3] = host::h_words("FRI/leaf")[0];
+        /* lanes 4,5 = (f, s) */ init[6] = CH; init[7] = AB; init[8] = host::h_words("leaf")[0]; init[16] = host::h_tag("FSv1-TRANSCRIPT-INIT");
+        STARK_HIP(ctx, hipMalloc((void**)&ctx->leaf_init, sizeof(init)));
+        STARK_HIP(ctx, hipMemcpyAsync(ctx->leaf_init, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *out = ctx->leaf_init; return STARK_OK;
+}
+
+extern "C" {
+
+int32_t stark_version(void) { return 1; }
+
+int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
+    if (!out) return STARK_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return STARK_ERR_HIP;   // no device => no product path
+    if (hipSetDevice(device) != hipSuccess) return STARK_ERR_HIP;
+    stark_ctx* c = new stark_ctx(); c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return STARK_ERR_HIP; } c->own_stream = true; }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return STARK_ERR_HIP; }
+    // allow the full 160 KiB of LDS per workgroup for the kernels that stage through it
+    (void)hipFuncSetAttribute((const void*)k_leaf_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_hash_ds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_permute_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_tr_hash, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_hash_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    *out = c; return STARK_OK;
+}
+int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
+    if (!ctx) return STARK_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
+    stark::ntt_plans_free(ctx);
+    if (ctx->tparams) stark_poseidon_params_free(ctx->tparams);
+    for (auto& kv : ctx->merkle_params) stark_poseidon_params_free(kv.second);
+    for (auto& kv : ctx->tr_frames) (void)hipFree(kv.second);
+    if (ctx->leaf_init) (void)hipFree(ctx->leaf_init);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0); if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx; return STARK_OK;
+}
+int32_t stark_ctx_sync(stark_ctx_t* ctx) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
+const char* stark_last_error(stark_ctx_t* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr) { if (!ctx || !dptr) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 32)); return STARK_OK; }
+int32_t stark_free(stark_ctx_t* ctx, void* dptr) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); STARK_HIP(ctx, hipFree(dptr)); return STARK_OK; }
+int32_t stark_memcpy_h2d(stark_ctx_t* ctx, void* d, const void* s, size_t bytes) {
+    if (!ctx) return STARK_ERR_INVALID_ARG;
+    STARK_HIP(ctx, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
+int32_t stark_memcpy_d2h(stark_ctx_t* ctx, void* d, const void* s, size_t bytes) {
+    if (!ctx) return STARK_ERR_INVALID_ARG;
+    STARK_HIP(ctx, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
+int32_t stark_timer_start(stark_ctx_t* ctx) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream)); return STARK_OK; }
+int32_t stark_timer_stop_ms(stark_ctx_t* ctx, float* ms) {
+    if (!ctx || !ms) return STARK_ERR_INVALID_ARG;
+    STARK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream)); STARK_HIP(ctx, hipEventSynchronize(ctx->ev1)); STARK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1)); return STARK_OK; }
+
+// ---- constants ---------------------------------------------------------------------------------------
+int32_t stark_poseidon_params_upload(stark_ctx_t* ctx, int32_t t, int32_t rf, int32_t rp, const uint64_t* mds, const uint64_t* rc_full, const uint64_t* rc_partial, stark_params_t** out) {
+    if (!ctx || !mds || !rc_full || !rc_partial || !out || t < 2 || rf <= 0 || (rf & 1) || rp <= 0) return ctx ? ctx->fail(STARK_ERR_INVALID_ARG, "bad params") : STARK_ERR_INVALID_ARG;
+    host::PoseidonConsts c; c.t = t; c.rf = rf; c.rp = rp;
+    c.mds.resize((size_t)t * t); c.rc_full.resize((size_t)rf * t); c.rc_partial.resize(rp);
+    for (size_t i = 0; i < c.mds.size(); ++i) c.mds[i] = load_fr(mds + 4 * i);
+    for (size_t i = 0; i < c.rc_full.size(); ++i) c.rc_full[i] = load_fr(rc_full + 4 * i);
+    for (size_t i = 0; i < c.rc_partial.size(); ++i) c.rc_partial[i] = load_fr(rc_partial + 4 * i);
+    return params_from_consts(ctx, c, out);
+}
+int32_t stark_poseidon_params_for_width(stark_ctx_t* ctx, int32_t t, stark_params_t** out) {
+    if (!ctx || !out) return STARK_ERR_INVALID_ARG;
+    if (host::rp_for_width(t) < 0) return ctx->fail(STARK_ERR_UNSUPPORTED, "unsupported Poseidon width t; supported t in {9,17,33,65,129}");   // poseidon/src/lib.rs:127
+    return params_from_consts(ctx, host::consts_for_width(t), out);
+}
+int32_t stark_poseidon_params_t17_seed(stark_ctx_t* ctx, const uint8_t* seed, size_t n, stark_params_t** out) {
+    if (!ctx || !out || (!seed && n)) return STARK_ERR_INVALID_ARG;
+    return params_from_consts(ctx, host::derive_consts(std::string((const char*)seed, n), 17, 8, 64), out);
+}
+int32_t stark_poseidon_params_export(stark_params_t* p, int32_t* t, int32_t* rf, int32_t* rp, uint64_t* mds, uint64_t* rc_full, uint64_t* rc_partial) {
+    if (!p) return STARK_ERR_INVALID_ARG;
+    if (t) *t = p->ref.t; if (rf) *rf = p->ref.rf; if (rp) *rp = p->ref.rp;
+    if (mds) for (size_t i = 0; i < p->ref.mds.size(); ++i) store_fr(mds + 4 * i, p->ref.mds[i]);
+    if (rc_full) for (size_t i = 0; i < p->ref.rc_full.size(); ++i) store_fr(rc_full + 4 * i, p->ref.rc_full[i]);
+    if (rc_partial) for (size_t i = 0; i < p->ref.rc_partial.size(); ++i) store_fr(rc_partial + 4 * i, p->ref.rc_partial[i]);
+    return STARK_OK;
+}
+int32_t stark_poseidon_params_free(stark_params_t* p) { if (!p) return STARK_ERR_INVALID_ARG; if (p->blob) (void)hipFree(p->blob); delete p; return STARK_OK; }
+
+// ---- Poseidon ----------------------------------------------------------------------------------------
+int32_t stark_poseidon_permute_batch_dev(stark_ctx_t* ctx, stark_params_t* p, uint64_t* states, size_t n) {
+    if (!ctx || !p || (!states && n)) return STARK_ERR_INVALID_ARG;
+    if (!n) return STARK_OK;
+    const int block = poseidon_block(p->dev.t);
+    hipLaunchKernelGGL(k_permute_batch, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), ctx->stream, p->dev, as_fr(states), n);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+int32_t stark_poseidon_permute_batch(stark_ctx_t* ctx, stark_params_t* p, uint64_t* states, size_t n) {
+    if (!ctx || !p || (!states && n)) return STARK_ERR_INVALID_ARG;
+    size_t bytes = n * p->dev.t * sizeof(fr_t); DevBuf d; STARK_HIP(ctx, d.alloc(bytes));
+    STARK_HIP(ctx, hipMemcpyAsync(d.p, states, bytes, hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(stark_poseidon_permute_batch_dev(ctx, p, (uint64_t*)d.p, n));
+    STARK_HIP(ctx, hipMemcpyAsync(states, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+static int32_t hash_stream(stark_ctx_t* ctx, stark_params_t* p, int mode, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, const fr_t& tag, size_t n, uint64_t* out) {
+    DevBuf da, db, dout; STARK_HIP(ctx, da.alloc(n * na * sizeof(fr_t))); STARK_HIP(ctx, db.alloc(n * nb * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n * sizeof(fr_t)));
+    if (n * na) STARK_HIP(ctx, hipMemcpyAsync(da.p, a, n * na * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    if (n * nb) STARK_HIP(ctx, hipMemcpyAsync(db.p, b, n * nb * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    const int block = poseidon_block(p->dev.t);
+    hipLaunchKernelGGL(k_hash_stream, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), ctx->stream, p->dev, mode, da.fr(), na, db.fr(), nb, tag, n, dout.fr());
+    STARK_HIP(ctx, hipGetLastError());
+    STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+int32_t stark_poseidon_hash_with_ds_dynamic(stark_ctx_t* ctx, stark_params_t* p, const uint64_t* ds, size_t nds, const uint64_t* in, size_t cnt, size_t n, uint64_t* out) {
+    if (!ctx || !p || !out || (!ds && nds) || (!in && cnt)) return STARK_ERR_INVALID_ARG;
+    if (!n) return STARK_OK;
+    return hash_stream(ctx, p, 0, ds, nds, in, cnt, host::h_zero(), n, out);
+}
+int32_t stark_poseidon_hash_with_ds(stark_ctx_t* ctx, stark_params_t* p, const uint64_t* in, size_t cnt, const uint64_t* ds_tag, uint64_t* out) {
+    if (!ctx || !p || !out || !ds_tag || (!in && cnt)) return STARK_ERR_INVALID_ARG;
+    if (p->dev.t != 17) return ctx->fail(STARK_ERR_INVALID_ARG, "hash_with_ds is the fixed t=17 sponge");
+    return hash_stream(ctx, p, 1, nullptr, 0, in, cnt, load_fr(ds_tag), 1, out);
+}
+static int32_t launch_hash_ds(stark_ctx_t* ctx, stark_params_t* p, int mode, size_t arity, uint32_t level, uint64_t pos0, uint64_t label,
+                              const fr_t* in0, const fr_t* in1, size_t n_in, fr_t* out) {
+    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
+    J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
+    if (!J.n_out) return STARK_OK;
+    const int block = poseidon_block(p->dev.t);
+    hipLaunchKernelGGL(k_hash_ds, dim3((unsigned)((J.n_out + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), ctx->stream, p->dev, J, in0, in1, out);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+int32_t stark_poseidon_hash_ds_batch_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in, size_t n_in, uint64_t* out) {
+    if (!ctx || !p || !in || !out || arity == 0) return STARK_ERR_INVALID_ARG;
+    if (host::width_for_arity(arity) != p->dev.t) return ctx->fail(STARK_ERR_INVALID_ARG, "arity incompatible with Poseidon width");
+    return launch_hash_ds(ctx, p, 0, arity, level, pos0, label, as_fr(in), nullptr, n_in, as_fr(out));
+}
+int32_t stark_poseidon_hash_ds_batch(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in, size_t n_in, uint64_t* out) {
+    if (!ctx || !p || !in || !out || arity == 0) return STARK_ERR_INVALID_ARG;
+    size_t n_out = (n_in + arity - 1) / arity; DevBuf di, dout; STARK_HIP(ctx, di.alloc(n_in * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n_out * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(di.p, in, n_in * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(stark_poseidon_hash_ds_batch_dev(ctx, p, arity, level, pos0, label, (const uint64_t*)di.p, n_in, (uint64_t*)dout.p));
+    STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, n_out * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return STARK_OK;
+}
+int32_t stark_leaf_pair_hash_dev(stark_ctx_t* ctx, stark_params_t* tp, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h) {
+    if (!ctx || !tp || (!f && n) || (!h && n) || m == 0) return STARK_ERR_INVALID_ARG;
+    if (tp->dev.t != 17) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf hash uses the t=17 transcript permutation");
+    if (!n) return STARK_OK;
+    fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
+    const int block = 64;
+    hipLaunchKernelGGL(k_leaf_pair, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(17, block), ctx->stream, tp->dev, init, as_fr(f), as_fr(f_next), n, m, as_fr(h));
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+int32_t stark_leaf_pair_hash(stark_ctx_t* ctx, stark_params_t* tp, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h) {
+    if (!ctx || !tp || (!f && n) || (!h && n) || m == 0) return STARK_ERR_INVALID_ARG;
+    size_t nn = f_next ? (n + m - 1) / m : 0; DevBuf df, dn, dh;
+    STARK_HIP(ctx, df.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, dn.alloc(nn * sizeof(fr_t))); STARK_HIP(ctx, dh.alloc(n * sizeof(fr_t)));
+    if (n) STARK_HIP(ctx, hipMemcpyAsync(df.p, f, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    if (nn) STARK_HIP(ctx, hipMemcpyAsync(dn.p, f_next, nn * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(stark_leaf_pair_hash_dev(ctx, tp, (const uint64_t*)df.p, f_next ? (const uint64_t*)dn.p : nullptr, n, m, (uint64_t*)dh.p));
+    if (n) STARK_HIP(ctx, hipMemcpyAsync(h, dh.p, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+int32_t stark_tr_hash_fields_tagged_dev(stark_ctx_t* ctx, stark_params_t* tp, const char* tag, const uint64_t* fields, size_t k, size_t n, uint64_t* out) {
+    if (!ctx || !tag || (!fields && k && n) || (!out && n)) return STARK_ERR_INVALID_ARG;
+    (void)tp;   // the transcript permutation is fixed (transcript/src/lib.rs:44-46); the handle is accepted for API symmetry
+    return tr_hash_dev(ctx, tag, as_fr(fields), k, n, as_fr(out));
+}
+int32_t stark_tr_hash_fields_tagged(stark_ctx_t* ctx, stark_params_t* tp, const char* tag, const uint64_t* fields, size_t k, size_t n, uint64_t* out) {
+    if (!ctx || !tag || (!fields && k && n) || (!out && n)) return STARK_ERR_INVALID_ARG;
+    DevBuf di, dout; STARK_HIP(ctx, di.alloc(n * k * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n * sizeof(fr_t)));
+    if (n * k) STARK_HIP(ctx, hipMemcpyAsync(di.p, fields, n * k * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(stark_tr_hash_fields_tagged_dev(ctx, tp, tag, (const uint64_t*)di.p, k, n, (uint64_t*)dout.p));
+    if (n) STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+
+// ---- Merkle ------------------------------------------------------------------------------------------
+int32_t stark_merkle_build_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t label, const uint64_t* leaves, size_t n, int32_t pairs, const uint64_t* cp,
+                               uint64_t first_pos, uint32_t level0, int32_t stop_at_len, stark_tree_t** out) {
+    if (!ctx || !p || !leaves || !out || arity == 0 || (pairs && !cp)) return ctx ? ctx->fail(STARK_ERR_INVALID_ARG, "bad merkle args") : STARK_ERR_INVALID_ARG;
+    if (n == 0) return ctx->fail(STARK_ERR_INVALID_ARG, "no leaves");                                                 // merkle/src/lib.rs:148
+    if (host::width_for_arity(arity) != p->dev.t) return ctx->fail(STARK_ERR_INVALID_ARG, "arity incompatible with Poseidon width");   // :155-161
+    if (arity == 1 && n > 1) return ctx->fail(STARK_ERR_UNSUPPORTED, "arity 1 with more than one leaf never terminates in the reference");
+    stark_tree* T = new stark_tree(); T->ctx = ctx; T->p = p; T->arity = arity; T->label = label;
+    auto bail = [&](int32_t rc) { delete T; return rc; };
+    fr_t* l0 = nullptr;
+    if (hipMalloc((void**)&l0, n * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "merkle level 0"));
+    T->levels.push_back(l0); T->lens.push_back(n); T->owned.push_back(1);
+    if (pairs) { int32_t rc = launch_hash_ds(ctx, p, 1, arity, 0xFFFFFFFFu, first_pos, label, as_fr(leaves), as_fr(cp), n, l0); if (rc) return bail(rc); }
+    else if (hipMemcpyAsync(l0, leaves, n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "copy leaves"));
+    uint32_t level = level0; uint64_t pos = first_pos; size_t stop = stop_at_len > 0 ? (size_t)stop_at_len : 1;
+    while (T->lens.back() > stop) {
+        size_t len = T->lens.back(), nn = (len + arity - 1) / arity;
+        if (pos % arity) return bail(ctx->fail(STARK_ERR_INVALID_ARG, "shard offset not aligned to the arity"));
+        pos /= arity;
+        fr_t* nx = nullptr; if (hipMalloc((void**)&nx, nn * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "merkle level"));
+        T->levels.push_back(nx); T->lens.push_back(nn); T->owned.push_back(1);
+        int32_t rc = launch_hash_ds(ctx, p, 0, arity, level, pos, label, T->levels[T->levels.size() - 2], nullptr, len, nx); if (rc) return bail(rc);
+        level += 1;
+    }
+    *out = T; return STARK_OK;
+}
+int32_t stark_merkle_build(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t label, const uint64_t* leaves, size_t n, int32_t pairs, const uint64_t* cp, stark_tree_t** out) {
+    if (!ctx || !p || !leaves || !out || (pairs && !cp)) return STARK_ERR_INVALID_ARG;
+    if (n == 0) return ctx->fail(STARK_ERR_INVALID_ARG, "no leaves");
+    DevBuf dl, dc; STARK_HIP(ctx, dl.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(dl.p, leaves, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    if (pairs) { STARK_HIP(ctx, dc.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(dc.p, cp, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
+    STARK_TRY(stark_merkle_build_dev(ctx, p, arity, label, (const uint64_t*)dl.p, n, pairs, pairs ? (const uint64_t*)dc.p : nullptr, 0, 0, 0, out));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+int32_t stark_merkle_num_levels(stark_tree_t* t) { return t ? (int32_t)t->levels.size() : STARK_ERR_INVALID_ARG; }
+size_t stark_merkle_level_len(stark_tree_t* t, int32_t lvl) { return (t && lvl >= 0 && (size_t)lvl < t->lens.size()) ? t->lens[lvl] : 0; }
+const uint64_t* stark_merkle_level_dev(stark_tree_t* t, int32_t lvl) { return (t && lvl >= 0 && (size_t)lvl < t->levels.size()) ? (const uint64_t*)t->levels[lvl] : nullptr; }
+int32_t stark_merkle_level(stark_tree_t* t, int32_t lvl, uint64_t* out) {
+    if (!t || !out || lvl < 0 || (size_t)lvl >= t->levels.size()) return STARK_ERR_INVALID_ARG;
+    stark_ctx* ctx = t->ctx;
+    STARK_HIP(ctx, hipMemcpyAsync(out, t->levels[lvl], t->lens[lvl] * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+int32_t stark_merkle_root(stark_tree_t* t, uint64_t* out4) {
+    if (!t || !out4) return STARK_ERR_INVALID_ARG;
+    if (t->lens.back() != 1) return t->ctx->fail(STARK_ERR_INVALID_ARG, "partial (sharded) tree has no root");
+    return stark_merkle_level(t, (int32_t)t->levels.size() - 1, out4);
+}
+int32_t stark_merkle_gather(stark_tree_t* t, int32_t lvl, const size_t* idx, size_t k, uint64_t* out) {
+    if (!t || (!idx && k) || (!out && k) || lvl < 0 || (size_t)lvl >= t->levels.size()) return STARK_ERR_INVALID_ARG;
+    stark_ctx* ctx = t->ctx; if (!k) return STARK_OK;
+    for (size_t i = 0; i < k; ++i) if (idx[i] >= t->lens[lvl]) return ctx->fail(STARK_ERR_INVALID_ARG, "gather index out of range");
+    DevBuf di, dout; STARK_HIP(ctx, di.alloc(k * 8)); STARK_HIP(ctx, dout.alloc(k * sizeof(fr_t)));
+    std::vector<uint64_t> ix(idx, idx + k);
+    STARK_HIP(ctx, hipMemcpyAsync(di.p, ix.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream, t->levels[lvl], (const uint64_t*)di.p, (uint64_t)k, dout.fr());
+    STARK_HIP(ctx, hipGetLastError());
+    STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, k * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+int32_t stark_merkle_free(stark_tree_t* t) { if (!t) return STARK_ERR_INVALID_ARG; (void)hipStreamSynchronize(t->ctx->stream); delete t; return STARK_OK; }
+
+}  // extern "C"
+
+// open_union_of_paths (merkle/src/lib.rs:246-315): host index logic + device gathers of the siblings.
+namespace stark {
+int32_t merkle_open_host(stark_tree* t, const std::vector<size_t>& indices, MerkleProofHost& pr) {
+    stark_ctx* ctx = t->ctx;
+    if (indices.empty()) return ctx->fail(STARK_ERR_INVALID_ARG, "open_many: empty indices");                           // :247
+    if (t->lens.back() != 1) return ctx->fail(STARK_ERR_INVALID_ARG, "cannot open a partial tree");
+    std::vector<size_t> cur = indices; std::sort(cur.begin(), cur.end()); cur.erase(std::unique(cur.begin(), cur.end()), cur.end());
+    if (cur.back() >= t->lens[0]) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf index out of range");
+    pr.arity = t->arity; pr.indices = cur;
+    const size_t arity = t->arity, height = t->levels.size() - 1;
+    for (size_t level = 0; level < height; ++level) {
+        const size_t len = t->lens[level];
+        std::vector<size_t> want; std::vector<uint8_t> gs;
+        size_t i = 0;
+        while (i < cur.size()) {                       // cur is sorted: one group per distinct parent
+            size_t parent = cur[i] / arity, base = parent * arity, end = std::min(base + arity, len);
+            gs.push_back((uint8_t)(end - base));
+            for (size_t c = base; c < end; ++c) { if (i < cur.size() && cur[i] == c) ++i; else want.push_back(c); }
+        }
+        std::vector<fr_t> sib(want.size());
+        if (!want.empty()) STARK_TRY(stark_merkle_gather(t, (int32_t)level, want.data(), want.size(), (uint64_t*)sib.data()));
+        pr.siblings.push_back(std::move(sib)); pr.group_sizes.push_back(std::move(gs));
+        std::vector<size_t> nx; for (size_t x : cur) { size_t q = x / arity; if (nx.empty() || nx.back() != q) nx.push_back(q); }
+        cur.swap(nx);
+    }
+    return STARK_OK;
+}
+void enc_u64(std::vector<uint8_t>& b, uint64_t x) { for (int j = 0; j < 8; ++j) b.push_back((uint8_t)(x >> (8 * j))); }
+void enc_fr(std::vector<uint8_t>& b, const fr_t& x) { uint8_t t[32]; host::h_to_bytes_le(x, t); b.insert(b.end(), t, t + 32); }
+void enc_idxs(std::vector<uint8_t>& b, const std::vector<size_t>& v) { enc_u64(b, v.size()); for (size_t x : v) enc_u64(b, x); }
+void enc_mproof(std::vector<uint8_t>& b, const MerkleProofHost& p) {
+    enc_idxs(b, p.indices);
+    enc_u64(b, p.siblings.size()); for (auto& l : p.siblings) { enc_u64(b, l.size()); for (auto& x : l) enc_fr(b, x); }
+    enc_u64(b, p.group_sizes.size()); for (auto& l : p.group_sizes) { enc_u64(b, l.size()); for (uint8_t x : l) b.push_back(x); }
+    enc_u64(b, p.arity);
+}
+}  // namespace stark
+
+extern "C" int32_t stark_merkle_open(stark_tree_t* t, const size_t* idx, size_t k, uint8_t* buf, size_t cap, size_t* len) {
+    if (!t || !len || (!idx && k)) return STARK_ERR_INVALID_ARG;
+    MerkleProofHost pr; STARK_TRY(merkle_open_host(t, std::vector<size_t>(idx, idx + k), pr));
+    std::vector<uint8_t> b; enc_mproof(b, pr);
+    *len = b.size();
+    if (buf) { if (cap < b.size()) return t->ctx->fail(STARK_ERR_INVALID_ARG, "buffer too small"); memcpy(buf, b.data(), b.size()); }
+    return STARK_OK;
+}

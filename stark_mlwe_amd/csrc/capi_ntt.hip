@@ -1,0 +1,233 @@
+// stark_mlwe_amd/csrc/capi_ntt.hip — NTT / iNTT / LDE entry points and plans (crates/fft/src/lib.rs:6-32),
+// the per-GPU building blocks of the multi-GPU six-step NTT, and the synthetic-input generator.
+#include <algorithm>
+#include <cstring>
+#include "ctx.hpp"
+#include "fri_dev.hpp"
+
+using namespace stark;
+
+namespace stark {
+
+struct DevTable { fr_t* lo = nullptr; fr_t* hi = nullptr; int lo_bits = 0; PowTable view() const { return PowTable{lo, hi, lo_bits}; } };
+struct NttPlan {
+    int field = 0, log_n = 0; bool inverse = false;
+    int P = 1; int log_b[3] = {0, 0, 0};
+    fr_t* stage_tw[3] = {nullptr, nullptr, nullptr};   // w_B^(+-e), e < B/2 per pass
+    DevTable root;                                    // powers of w_N^(+-1)
+    fr_t* scale = nullptr;                            // n^-1 (inverse plans)
+    // coset cache (one coset value at a time)
+    bool have_coset = false; fr_t coset; DevTable coset_tab;
+    ~NttPlan() {
+        for (auto p : stage_tw) if (p) (void)hipFree(p);
+        if (root.lo) (void)hipFree(root.lo); if (root.hi) (void)hipFree(root.hi); if (scale) (void)hipFree(scale);
+        if (coset_tab.lo) (void)hipFree(coset_tab.lo); if (coset_tab.hi) (void)hipFree(coset_tab.hi);
+    }
+};
+
+}  // namespace stark
+
+static const size_t kMaxLds = 160 * 1024;
+
+template <class F>
+static int32_t fill_table(stark_ctx* ctx, const fr_t& g, const fr_t& c0, int lo_bits, int hi_bits, DevTable& T) {
+    if (T.lo) { (void)hipFree(T.lo); T.lo = nullptr; } if (T.hi) { (void)hipFree(T.hi); T.hi = nullptr; }
+    STARK_HIP(ctx, hipMalloc((void**)&T.lo, ((size_t)1 << lo_bits) * sizeof(fr_t))); STARK_HIP(ctx, hipMalloc((void**)&T.hi, ((size_t)1 << hi_bits) * sizeof(fr_t)));
+    T.lo_bits = lo_bits;
+    uint64_t tot = (1ull << lo_bits) + (1ull << hi_bits);
+    hipLaunchKernelGGL(k_fill_pow_table<F>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, T.lo, T.hi, lo_bits, hi_bits, g, c0);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+
+template <class F>
+static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) {
+    uint64_t key = ((uint64_t)F::ID << 40) | ((uint64_t)log_n << 8) | (inverse ? 1 : 0);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) { *out = it->second; return STARK_OK; }
+    NttPlan* p = new NttPlan(); p->field = F::ID; p->log_n = log_n; p->inverse = inverse;
+    if (log_n <= 10) { p->P = 1; p->log_b[0] = log_n; }
+    else if (log_n <= 20) { p->P = 2; p->log_b[0] = (log_n + 1) / 2; p->log_b[1] = log_n - p->log_b[0]; }
+    else { p->P = 3; p->log_b[0] = (log_n + 2) / 3; p->log_b[1] = (log_n - p->log_b[0] + 1) / 2; p->log_b[2] = log_n - p->log_b[0] - p->log_b[1]; }
+    auto bail = [&](int32_t rc) { delete p; return rc; };
+    fr_t w = fr_root_of_unity<F>((unsigned)log_n); if (inverse) w = fr_inv<F>(w);
+    int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
+    { int32_t rc = fill_table<F>(ctx, w, fr_one<F>(), lo_bits, hi_bits, p->root); if (rc) return bail(rc); }
+    for (int i = 0; i < p->P; ++i) {
+        int lb = p->log_b[i]; fr_t wb = fr_root_of_unity<F>((unsigned)lb); if (inverse) wb = fr_inv<F>(wb);
+        DevTable T; int32_t rc = fill_table<F>(ctx, wb, fr_one<F>(), lb > 0 ? lb - 1 : 0, 0, T); if (rc) return bail(rc);
+        p->stage_tw[i] = T.lo; (void)hipFree(T.hi);
+    }
+    if (inverse) {
+        fr_t ninv = fr_inv<F>(fr_from_u64<F>(1ull << log_n));
+        if (hipMalloc((void**)&p->scale, sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "ntt scale"));
+        if (hipMemcpyAsync(p->scale, &ninv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "ntt scale copy"));
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "sync"));
+    }
+    ctx->plans[key] = p; *out = p; return STARK_OK;
+}
+
+static inline size_t ntt_lds_bytes(int log_b, int log_c) { return (((size_t)2 << (log_b + log_c)) + ((size_t)1 << log_b)) * 16; }
+static inline int pick_log_c(int log_b, int cap) { int lc = log_b >= 10 ? 2 : std::max(2, 11 - log_b); return std::max(0, std::min(lc, cap)); }
+
+template <class F>
+static int32_t launch_strided(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, const fr_t* src, fr_t* dst) {
+    size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
+    if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
+    uint64_t tiles = total_elems >> (A.log_b + A.log_c);
+    hipLaunchKernelGGL(k_ntt_strided<F>, dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+template <class F>
+static int32_t launch_last(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, const fr_t* src, fr_t* dst) {
+    size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
+    if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
+    uint64_t tiles = total_elems >> (A.log_b + A.log_c);
+    hipLaunchKernelGGL(k_ntt_last<F>, dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+
+// `batch` vectors of 2^log_n elements each, contiguous.  data is transformed in place (scratch from the context).
+template <class F>
+static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bool inverse, const fr_t* coset, const fr_t* scale_override_dev) {
+    if (log_n < 0 || log_n > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "log_n out of range");
+    if (batch == 0) return STARK_OK;
+    if (log_n == 0) {   // size-1 transform: identity (n^-1 = 1, g^0 = 1)
+        return STARK_OK;
+    }
+    NttPlan* p = nullptr; STARK_TRY(get_plan<F>(ctx, log_n, inverse, &p));
+    PowTable none{nullptr, nullptr, 0};
+    PowTable pre = none, post = none;
+    if (coset) {
+        if (!p->have_coset || !fr_eq(p->coset, *coset)) {
+            int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
+            if (!inverse) STARK_TRY(fill_table<F>(ctx, *coset, fr_one<F>(), lo_bits, hi_bits, p->coset_tab));                       // g^j
+            else STARK_TRY(fill_table<F>(ctx, fr_inv<F>(*coset), fr_inv<F>(fr_from_u64<F>(1ull << log_n)), lo_bits, hi_bits, p->coset_tab));   // n^-1 g^-k
+            p->coset = *coset; p->have_coset = true;
+        }
+        if (!inverse) pre = p->coset_tab.view(); else post = p->coset_tab.view();
+    }
+    const uint64_t total = batch << log_n;
+    fr_t* scratch = nullptr;
+    if (p->P > 1) { void* s = nullptr; STARK_TRY(ctx_scratch(ctx, total * sizeof(fr_t), &s)); scratch = (fr_t*)s; }
+    NttPassArgs A; memset(&A, 0, sizeof(A));
+    A.log_n = log_n; A.root = p->root.view(); A.pre = none; A.post = none; A.scale = nullptr; A.rest0 = 0; A.log_vec = log_n;
+    const fr_t* src = data;
+    int rem = log_n;                       // log2 of the current sub-problem size
+    for (int i = 0; i + 1 < p->P; ++i) {   // strided passes
+        A.log_b = p->log_b[i]; A.log_m = rem; A.stride = 1ull << (rem - A.log_b);
+        A.log_c = pick_log_c(A.log_b, rem - A.log_b);
+        A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none;
+        STARK_TRY(launch_strided<F>(ctx, A, total, src, scratch));
+        src = scratch; rem -= A.log_b;
+    }
+    A.pre = (p->P == 1) ? pre : none;
+    A.log_b = p->log_b[p->P - 1]; A.stage_tw = p->stage_tw[p->P - 1];
+    A.log_b1 = p->P >= 2 ? p->log_b[0] : 0; A.log_b2 = p->P == 3 ? p->log_b[1] : 0;
+    A.log_c = p->P == 1 ? 0 : pick_log_c(A.log_b, A.log_b1);
+    A.post = post; A.scale = post.lo ? nullptr : (scale_override_dev ? scale_override_dev : (inverse ? p->scale : nullptr));
+    STARK_TRY(launch_last<F>(ctx, A, total, src, data));
+    return STARK_OK;
+}
+
+template <class F>
+static int32_t lde_run(stark_ctx* ctx, const fr_t* evals, int log_n, int log_blowup, const fr_t* coset, fr_t* out) {
+    const uint64_t n = 1ull << log_n, N = n << log_blowup;
+    STARK_HIP(ctx, hipMemcpyAsync(out, evals, n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
+    STARK_TRY(ntt_run<F>(ctx, out, log_n, 1, true, nullptr, nullptr));                       // evaluations on H -> coefficients
+    if (N > n) { hipLaunchKernelGGL(k_zero_fill<F>, dim3((unsigned)((N - n + 255) / 256)), dim3(256), 0, ctx->stream, out + n, N - n); STARK_HIP(ctx, hipGetLastError()); }
+    fr_t one = fr_one<F>(); bool unit = !coset || fr_eq(*coset, one);
+    return ntt_run<F>(ctx, out, log_n + log_blowup, 1, false, unit ? nullptr : coset, nullptr);   // coefficients -> coset evaluations on the larger domain
+}
+
+void stark::ntt_plans_free(stark_ctx* ctx) { for (auto& kv : ctx->plans) delete kv.second; ctx->plans.clear(); }
+
+static void set_ntt_attrs() {
+    static bool done = false; if (done) return; done = true;
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided<PallasFr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_last<PallasFr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided<Bls12381Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_last<Bls12381Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+}
+
+// Multi-GPU phase A: column NTTs of size 2^log_rows over a row-major [2^log_rows][ncols] slab whose first
+// column has global index col0, followed by the twiddle w_N^(col_global * k), N = 2^log_n.  In place.
+template <class F>
+static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t ncols, uint64_t col0, int log_n, bool inverse) {
+    if (log_rows < 1 || log_rows > 10) return ctx->fail(STARK_ERR_UNSUPPORTED, "column NTT size must be 2..1024");
+    if (ncols == 0 || (ncols & (ncols - 1))) return ctx->fail(STARK_ERR_INVALID_ARG, "ncols must be a power of two");
+    NttPlan* big = nullptr; STARK_TRY(get_plan<F>(ctx, log_n, inverse, &big));        // root table of w_N
+    NttPlan* sm = nullptr; STARK_TRY(get_plan<F>(ctx, log_rows, inverse, &sm));       // stage twiddles of w_R (P == 1 plan)
+    NttPassArgs A; memset(&A, 0, sizeof(A));
+    int log_cols = 0; while ((1ull << log_cols) < ncols) ++log_cols;
+    A.log_b = log_rows; A.log_c = pick_log_c(log_rows, log_cols); A.log_n = log_n; A.stride = ncols; A.log_m = log_n;
+    A.stage_tw = sm->stage_tw[0]; A.root = big->root.view(); A.rest0 = col0;
+    return launch_strided<F>(ctx, A, (uint64_t)ncols << log_rows, slab, slab);
+}
+extern "C" {
+
+int32_t stark_ntt_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4) {
+    if (!ctx || !data) return STARK_ERR_INVALID_ARG;
+    set_ntt_attrs();
+    fr_t cs; if (coset4) cs = load_fr(coset4);
+    if (field_id == STARK_FIELD_PALLAS_FR) return ntt_run<PallasFr>(ctx, as_fr(data), (int)log_n, 1, inverse != 0, coset4 ? &cs : nullptr, nullptr);
+    if (field_id == STARK_FIELD_BLS12_381_FR) return ntt_run<Bls12381Fr>(ctx, as_fr(data), (int)log_n, 1, inverse != 0, coset4 ? &cs : nullptr, nullptr);
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+int32_t stark_ntt(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4) {
+    if (!ctx || !data || log_n > 30) return STARK_ERR_INVALID_ARG;
+    size_t bytes = ((size_t)1 << log_n) * sizeof(fr_t); DevBuf d; STARK_HIP(ctx, d.alloc(bytes));
+    STARK_HIP(ctx, hipMemcpyAsync(d.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(stark_ntt_dev(ctx, field_id, (uint64_t*)d.p, log_n, inverse, coset4));
+    STARK_HIP(ctx, hipMemcpyAsync(data, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+int32_t stark_lde_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* coset4, uint64_t* out) {
+    if (!ctx || !evals || !out || log_n + log_blowup > 30) return STARK_ERR_INVALID_ARG;
+    set_ntt_attrs();
+    fr_t cs; if (coset4) cs = load_fr(coset4);
+    if (field_id == STARK_FIELD_PALLAS_FR) return lde_run<PallasFr>(ctx, as_fr(evals), (int)log_n, (int)log_blowup, coset4 ? &cs : nullptr, as_fr(out));
+    if (field_id == STARK_FIELD_BLS12_381_FR) return lde_run<Bls12381Fr>(ctx, as_fr(evals), (int)log_n, (int)log_blowup, coset4 ? &cs : nullptr, as_fr(out));
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+int32_t stark_lde(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* coset4, uint64_t* out) {
+    if (!ctx || !evals || !out || log_n + log_blowup > 30) return STARK_ERR_INVALID_ARG;
+    size_t n = (size_t)1 << log_n, N = n << log_blowup; DevBuf di, dout; STARK_HIP(ctx, di.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(N * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(di.p, evals, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(stark_lde_dev(ctx, field_id, (const uint64_t*)di.p, log_n, log_blowup, coset4, (uint64_t*)dout.p));
+    STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, N * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+
+int32_t stark_ntt_columns_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, int32_t inverse) {
+    if (!ctx || !slab) return STARK_ERR_INVALID_ARG;
+    set_ntt_attrs();
+    if (field_id == STARK_FIELD_PALLAS_FR) return columns_run<PallasFr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, inverse != 0);
+    if (field_id == STARK_FIELD_BLS12_381_FR) return columns_run<Bls12381Fr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, inverse != 0);
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+// Multi-GPU phase B: `nrows` contiguous NTTs of size 2^log_cols.  scale4 (optional) multiplies every output
+// (the caller passes N^-1 of the FULL transform for an inverse; the per-row n^-1 is not applied).
+int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t nrows, size_t log_cols, int32_t inverse, const uint64_t* scale4) {
+    if (!ctx || !slab) return STARK_ERR_INVALID_ARG;
+    set_ntt_attrs();
+    DevBuf sc; fr_t one_f;
+    if (scale4) { fr_t s = load_fr(scale4); STARK_HIP(ctx, sc.alloc(sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &s, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    else if (inverse) {   // suppress the plan's per-row n^-1: multiply by one
+        one_f = field_id == STARK_FIELD_PALLAS_FR ? fr_one<PallasFr>() : fr_one<Bls12381Fr>();
+        STARK_HIP(ctx, sc.alloc(sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &one_f, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int32_t rc;
+    if (field_id == STARK_FIELD_PALLAS_FR) rc = ntt_run<PallasFr>(ctx, as_fr(slab), (int)log_cols, nrows, inverse != 0, nullptr, sc.p ? sc.fr() : nullptr);
+    else if (field_id == STARK_FIELD_BLS12_381_FR) rc = ntt_run<Bls12381Fr>(ctx, as_fr(slab), (int)log_cols, nrows, inverse != 0, nullptr, sc.p ? sc.fr() : nullptr);
+    else return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+    if (rc) return rc;
+    if (sc.p) STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // sc freed on return
+    return STARK_OK;
+}
+
+int32_t stark_synth_column_dev(stark_ctx_t* ctx, uint64_t seed, uint64_t col, size_t i0, size_t n, uint64_t* out) {
+    if (!ctx || (!out && n)) return STARK_ERR_INVALID_ARG;
+    if (!n) return STARK_OK;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, col, (uint64_t)i0, (uint64_t)n, as_fr(out));
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// stark_mlwe_amd/csrc/ctx.hpp — internal objects behind the opaque C-ABI handles (product code).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/stark_mlwe.h"
+#include "fr.hpp"
+#include "host_util.hpp"
+#include "poseidon_params.hpp"
+#include "ntt_dev.hpp"
+
+namespace stark {
+
+struct NttPlan;
+
+}  // namespace stark
+
+struct stark_params {
+    stark_ctx* ctx = nullptr;
+    stark::host::PoseidonConsts ref;     // reference-form constants (as uploaded / derived)
+    stark::host::KernelConsts kc;        // kernel-form constants
+    stark::fr_t* blob = nullptr;         // one device allocation holding all tables
+    stark::PoseidonDev dev{};            // device pointers into `blob`
+};
+
+struct stark_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // lazily created constants
+    stark_params* tparams = nullptr;                 // transcript params (t=17, "POSEIDON-T17-X5-TRANSCRIPT")
+    std::map<int, stark_params*> merkle_params;      // poseidon_params_for_width(t)
+    stark::fr_t* leaf_init = nullptr;                // 17-lane template of hash_leaf_pair (device)
+    std::map<std::string, stark::fr_t*> tr_frames;   // per-tag transcript prefix/suffix frames (device): [prefix.., suffix..]
+    std::map<std::string, std::pair<int, int>> tr_frame_dims;
+    // scratch
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    // NTT plans
+    std::map<uint64_t, stark::NttPlan*> plans;
+
+    int32_t fail(int32_t code, const std::string& msg) { err = msg; return code; }
+};
+
+struct stark_tree {
+    stark_ctx* ctx = nullptr; stark_params* p = nullptr;
+    size_t arity = 0; uint64_t label = 0;
+    std::vector<stark::fr_t*> levels; std::vector<size_t> lens; std::vector<char> owned;
+    ~stark_tree() { for (size_t i = 0; i < levels.size(); ++i) if (owned[i] && levels[i]) (void)hipFree(levels[i]); }
+};
+
+
+#define STARK_HIP(ctx, call)                                                                                     \
+    do {                                                                                                         \
+        hipError_t e__ = (call);                                                                                 \
+        if (e__ != hipSuccess) return (ctx)->fail(e__ == hipErrorOutOfMemory ? STARK_ERR_OOM : STARK_ERR_HIP,     \
+                                                  std::string(#call) + ": " + hipGetErrorString(e__));           \
+    } while (0)
+#define STARK_TRY(expr) do { int32_t rc__ = (expr); if (rc__ != STARK_OK) return rc__; } while (0)
+
+namespace stark {
+
+inline const fr_t* as_fr(const uint64_t* p) { return reinterpret_cast<const fr_t*>(p); }
+inline fr_t* as_fr(uint64_t* p) { return reinterpret_cast<fr_t*>(p); }
+inline fr_t load_fr(const uint64_t* p) { fr_t x; for (int i = 0; i < 4; ++i) { x.v[2 * i] = (uint32_t)p[i]; x.v[2 * i + 1] = (uint32_t)(p[i] >> 32); } return x; }
+inline void store_fr(uint64_t* p, const fr_t& x) { for (int i = 0; i < 4; ++i) p[i] = (uint64_t)x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32); }
+
+// RAII device buffer used inside entry points (freed on every return path).
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 32); }
+    fr_t* fr() const { return reinterpret_cast<fr_t*>(p); }
+    void* release() { void* q = p; p = nullptr; return q; }
+};
+
+// MerkleProof (merkle/src/lib.rs:131-143) on the host side of the product + canonical encoders.
+struct MerkleProofHost { std::vector<size_t> indices; std::vector<std::vector<fr_t>> siblings; std::vector<std::vector<uint8_t>> group_sizes; size_t arity = 0; };
+int32_t merkle_open_host(stark_tree* t, const std::vector<size_t>& indices, MerkleProofHost& pr);
+void enc_u64(std::vector<uint8_t>& b, uint64_t x);
+void enc_fr(std::vector<uint8_t>& b, const fr_t& x);
+void enc_idxs(std::vector<uint8_t>& b, const std::vector<size_t>& v);
+void enc_mproof(std::vector<uint8_t>& b, const MerkleProofHost& p);
+
+// shared internal entry points (defined in capi_core.hip / capi_fri.hip / capi_ntt.hip)
+int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out);
+int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out);
+int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out);
+void ntt_plans_free(stark_ctx* ctx);
+int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev);
+int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out);   // one hash, host in/out
+
+}  // namespace stark

@@ -1,0 +1,115 @@
+// stark_mlwe_amd/csrc/hostcheck.cpp — DIAGNOSTIC library (libstark_mlwe_hostcheck.so), CPU-only.
+//
+// Instantiates, on the host, the SAME inline code the kernels are built from (fr.hpp arithmetic,
+// host_util.hpp constant derivation, poseidon_dev.hpp permutation / sponge bodies with a plain-array
+// state) so that `pytest -m "not gpu"` can check the product's host logic and kernel bodies against
+// the oracle without a GPU.  No product entry point loads or calls this library; it is not a
+// fallback: libstark_mlwe_hip.so fails with STARK_ERR_HIP when no device is present.
+#include <cstring>
+#include <vector>
+#include "fr.hpp"
+#include "host_util.hpp"
+#include "poseidon_dev.hpp"
+
+using namespace stark;
+
+static fr_t ld4(const uint64_t* p) { fr_t x; for (int i = 0; i < 4; ++i) { x.v[2 * i] = (uint32_t)p[i]; x.v[2 * i + 1] = (uint32_t)(p[i] >> 32); } return x; }
+static void st4(uint64_t* p, const fr_t& x) { for (int i = 0; i < 4; ++i) p[i] = (uint64_t)x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32); }
+
+struct HcParams { host::PoseidonConsts ref; host::KernelConsts kc; PoseidonDev dev; };
+static void bind(HcParams* P) {
+    P->kc = host::make_kernel_consts(P->ref);
+    P->dev.t = P->kc.t; P->dev.rf = P->kc.rf; P->dev.rp = P->kc.rp; P->dev.rc_full = P->kc.rc_full.data(); P->dev.rc_partial = P->kc.rc_partial.data();
+    P->dev.lu = P->kc.lu.data(); P->dev.lu_pre = P->kc.lu_pre.data(); P->dev.row0 = P->kc.row0.data(); P->dev.sparse = P->kc.sparse.data(); P->dev.mds = P->kc.mds.data();
+}
+
+extern "C" {
+
+// field: 0 Pallas, 1 BLS12-381.  op: 0 add, 1 sub, 2 mul, 3 inv, 4 from_u64(a[0]), 5 to_canonical, 6 root_of_unity(a[0]), 7 pow_u64(a, b[0])
+int hc_fr_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    fr_t x = ld4(a), y = b ? ld4(b) : x, z;
+    if (field == 0) {
+        switch (op) { case 0: z = fr_add<PallasFr>(x, y); break; case 1: z = fr_sub<PallasFr>(x, y); break; case 2: z = fr_mul<PallasFr>(x, y); break; case 3: z = fr_inv<PallasFr>(x); break;
+            case 4: z = fr_from_u64<PallasFr>(a[0]); break; case 5: z = fr_to_canonical<PallasFr>(x); break; case 6: z = fr_root_of_unity<PallasFr>((unsigned)a[0]); break;
+            case 7: z = fr_pow_u64<PallasFr>(x, b[0]); break; default: return -1; }
+    } else {
+        switch (op) { case 0: z = fr_add<Bls12381Fr>(x, y); break; case 1: z = fr_sub<Bls12381Fr>(x, y); break; case 2: z = fr_mul<Bls12381Fr>(x, y); break; case 3: z = fr_inv<Bls12381Fr>(x); break;
+            case 4: z = fr_from_u64<Bls12381Fr>(a[0]); break; case 5: z = fr_to_canonical<Bls12381Fr>(x); break; case 6: z = fr_root_of_unity<Bls12381Fr>((unsigned)a[0]); break;
+            case 7: z = fr_pow_u64<Bls12381Fr>(x, b[0]); break; default: return -1; }
+    }
+    st4(out, z); return 0;
+}
+int hc_blake3(const uint8_t* p, size_t n, uint8_t* out32) { host::Blake3::hash(p, n, out32); return 0; }
+int hc_chacha12_u64s(const uint8_t* seed32, size_t n, uint64_t* out) { host::ChaCha12Rng r(seed32); for (size_t i = 0; i < n; ++i) out[i] = r.next_u64(); return 0; }
+int hc_from_le_bytes_mod_order(const uint8_t* b, size_t n, uint64_t* out) { st4(out, host::h_from_le_bytes_mod_order(b, n)); return 0; }
+int hc_to_bytes_le(const uint64_t* a, uint8_t* out32) { host::h_to_bytes_le(ld4(a), out32); return 0; }
+
+// kind 0: consts_for_width(t); 1: transcript; 2: t17 from seed string
+void* hc_params_new(int kind, int t, const char* seed) {
+    HcParams* P = new HcParams();
+    P->ref = kind == 0 ? host::consts_for_width(t) : kind == 1 ? host::consts_transcript() : host::derive_consts(seed, 17, 8, 64);
+    bind(P); return P;
+}
+int hc_params_ok(void* h) { return ((HcParams*)h)->kc.ok ? 1 : 0; }
+void hc_params_free(void* h) { delete (HcParams*)h; }
+int hc_params_export(void* h, uint64_t* mds, uint64_t* rc_full, uint64_t* rc_partial) {
+    HcParams* P = (HcParams*)h;
+    for (size_t i = 0; i < P->ref.mds.size(); ++i) st4(mds + 4 * i, P->ref.mds[i]);
+    for (size_t i = 0; i < P->ref.rc_full.size(); ++i) st4(rc_full + 4 * i, P->ref.rc_full[i]);
+    for (size_t i = 0; i < P->ref.rc_partial.size(); ++i) st4(rc_partial + 4 * i, P->ref.rc_partial[i]);
+    return 0;
+}
+// kernel-form permutation (LU + sparse) of nstates AoS states on the host
+int hc_permute_kernel_form(void* h, uint64_t* states, size_t n) {
+    HcParams* P = (HcParams*)h; int t = P->dev.t; std::vector<fr_t> st(t);
+    for (size_t i = 0; i < n; ++i) { for (int j = 0; j < t; ++j) st[j] = ld4(states + 4 * (i * t + j)); ArrayState s{st.data()}; permute_core(s, P->dev, false); for (int j = 0; j < t; ++j) st4(states + 4 * (i * t + j), st[j]); }
+    return 0;
+}
+// reference-form (dense) permutation on the host, from the same constants
+int hc_permute_dense(void* h, uint64_t* states, size_t n) {
+    HcParams* P = (HcParams*)h; int t = P->ref.t; std::vector<fr_t> st(t);
+    for (size_t i = 0; i < n; ++i) { for (int j = 0; j < t; ++j) st[j] = ld4(states + 4 * (i * t + j)); host::permute_dense(st.data(), P->ref); for (int j = 0; j < t; ++j) st4(states + 4 * (i * t + j), st[j]); }
+    return 0;
+}
+// kernel bodies on the host ---------------------------------------------------------------------------
+int hc_leaf_pair(void* tparams, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* hout) {
+    HcParams* P = (HcParams*)tparams;
+    const fr_t AB = host::h_tag("FSv1-ABSORB-BYTES"), CH = host::h_tag("FSv1-CHALLENGE");
+    fr_t init[17]; for (auto& x : init) x = host::h_zero();
+    init[0] = AB; init[1] = host::h_words("FRI/leaf/poseidon")[0]; init[2] = AB; init[3] = host::h_words("FRI/leaf")[0];
+    init[6] = CH; init[7] = AB; init[8] = host::h_words("leaf")[0]; init[16] = host::h_tag("FSv1-TRANSCRIPT-INIT");
+    fr_t st[17];
+    for (size_t i = 0; i < n; ++i) { ArrayState s{st}; st4(hout + 4 * i, leaf_pair_body(s, P->dev, init, ld4(f + 4 * i), f_next ? ld4(f_next + 4 * (i / m)) : host::h_zero())); }
+    return 0;
+}
+int hc_hash_ds_level(void* params, int mode, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in0, const uint64_t* in1, size_t n_in, uint64_t* out) {
+    HcParams* P = (HcParams*)params;
+    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
+    J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
+    std::vector<fr_t> a(n_in), b(in1 ? n_in : 0), st(P->dev.t);
+    for (size_t i = 0; i < n_in; ++i) { a[i] = ld4(in0 + 4 * i); if (in1) b[i] = ld4(in1 + 4 * i); }
+    for (size_t k = 0; k < J.n_out; ++k) { ArrayState s{st.data()}; st4(out + 4 * k, hash_ds_body(s, P->dev, J, a.data(), in1 ? b.data() : nullptr, k)); }
+    return 0;
+}
+int hc_tr_hash(void* tparams, const char* tag, const uint64_t* fields, size_t k, size_t n, uint64_t* out) {
+    HcParams* P = (HcParams*)tparams;
+    std::vector<fr_t> fr; const fr_t AB = host::h_tag("FSv1-ABSORB-BYTES"), CH = host::h_tag("FSv1-CHALLENGE");
+    fr.push_back(AB); for (auto& w : host::h_words("FRI/FS")) fr.push_back(w);
+    fr.push_back(AB); for (auto& w : host::h_words(tag)) fr.push_back(w);
+    int np = (int)fr.size();
+    fr.push_back(CH); fr.push_back(AB); for (auto& w : host::h_words("out")) fr.push_back(w);
+    TrJob J; J.prefix = fr.data(); J.np = np; J.suffix = fr.data() + np; J.ns = (int)fr.size() - np; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.k = k; J.n = n;
+    std::vector<fr_t> fl(n * k); for (size_t i = 0; i < n * k; ++i) fl[i] = ld4(fields + 4 * i);
+    fr_t st[17];
+    for (size_t i = 0; i < n; ++i) { ArrayState s{st}; st4(out + 4 * i, tr_hash_body(s, P->dev, J, fl.data(), i)); }
+    return 0;
+}
+int hc_hash_stream(void* params, int mode, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, const uint64_t* tag, size_t n, uint64_t* out) {
+    HcParams* P = (HcParams*)params;
+    std::vector<fr_t> av(n * na), bv(n * nb), st(P->dev.t);
+    for (size_t i = 0; i < n * na; ++i) av[i] = ld4(a + 4 * i); for (size_t i = 0; i < n * nb; ++i) bv[i] = ld4(b + 4 * i);
+    for (size_t k = 0; k < n; ++k) { ArrayState s{st.data()}; st4(out + 4 * k, hash_stream_body(s, P->dev, mode, av.data(), na, bv.data(), nb, tag ? ld4(tag) : host::h_zero(), k)); }
+    return 0;
+}
+
+}  // extern "C"

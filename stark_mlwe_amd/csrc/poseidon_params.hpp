@@ -1,0 +1,16 @@
+// stark_mlwe_amd/csrc/poseidon_params.hpp — device view of the Poseidon constants (kernel form).
+#pragma once
+#include "fr.hpp"
+namespace stark {
+struct PoseidonDev {           // device pointers to kernel-form constants (see host_util.hpp KernelConsts)
+    int t, rf, rp;
+    const fr_t* rc_full;       // rf*t
+    const fr_t* rc_partial;    // rp
+    const fr_t* lu;            // t*t  LU(M)
+    const fr_t* lu_pre;        // t*t  LU(B_1*M)
+    const fr_t* row0;          // t    M[0][*]
+    const fr_t* sparse;        // rp*(2t-1)
+    const fr_t* mds;           // t*t  reference form
+};
+
+}  // namespace stark

@@ -1,0 +1,71 @@
+"""ctypes wrapper of stark_mlwe_amd/libstark_mlwe_hostcheck.so (diagnostic host build of the product's inline code)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "stark_mlwe_amd", "libstark_mlwe_hostcheck.so")
+vp = C.c_void_p
+
+
+def P(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def A(x):
+    return np.ascontiguousarray(x, dtype=np.uint64)
+
+
+class HostCheck:
+    def __init__(self):
+        self.l = C.CDLL(PATH)
+        self.l.hc_params_new.restype = vp
+
+    def fr_op(self, field, op, a, b=None):
+        out = np.zeros(4, np.uint64); assert self.l.hc_fr_op(field, op, P(A(a)), P(None if b is None else A(b)), P(out)) == 0; return out
+
+    def blake3(self, data: bytes):
+        out = (C.c_uint8 * 32)(); buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+        self.l.hc_blake3(buf, C.c_size_t(len(data)), out); return bytes(out)
+
+    def chacha12_u64s(self, seed: bytes, n):
+        out = np.zeros(n, np.uint64); buf = (C.c_uint8 * 32).from_buffer_copy(seed); self.l.hc_chacha12_u64s(buf, C.c_size_t(n), P(out)); return out
+
+    def from_le_bytes_mod_order(self, b: bytes):
+        out = np.zeros(4, np.uint64); buf = (C.c_uint8 * len(b)).from_buffer_copy(b); self.l.hc_from_le_bytes_mod_order(buf, C.c_size_t(len(b)), P(out)); return out
+
+    def to_bytes_le(self, a):
+        out = (C.c_uint8 * 32)(); self.l.hc_to_bytes_le(P(A(a)), out); return bytes(out)
+
+    def params(self, kind, t=17, seed=b""):
+        return vp(self.l.hc_params_new(kind, t, seed))
+
+    def params_ok(self, h): return self.l.hc_params_ok(h)
+    def params_free(self, h): self.l.hc_params_free(h)
+
+    def params_export(self, h, t, rf, rp):
+        mds = np.zeros((t * t, 4), np.uint64); rcf = np.zeros((rf * t, 4), np.uint64); rcp = np.zeros((rp, 4), np.uint64)
+        self.l.hc_params_export(h, P(mds), P(rcf), P(rcp)); return mds, rcf, rcp
+
+    def permute_kernel_form(self, h, states, t):
+        s = A(states).copy(); self.l.hc_permute_kernel_form(h, P(s), C.c_size_t(s.size // (4 * t))); return s
+
+    def permute_dense(self, h, states, t):
+        s = A(states).copy(); self.l.hc_permute_dense(h, P(s), C.c_size_t(s.size // (4 * t))); return s
+
+    def leaf_pair(self, h, f, f_next, m):
+        f = A(f); out = np.zeros_like(f); self.l.hc_leaf_pair(h, P(f), P(None if f_next is None else A(f_next)), C.c_size_t(f.shape[0]), C.c_size_t(m), P(out)); return out
+
+    def hash_ds_level(self, h, mode, arity, level, pos0, label, in0, in1=None):
+        in0 = A(in0); n_in = in0.shape[0]; n_out = n_in if mode == 1 else (n_in + arity - 1) // arity; out = np.zeros((n_out, 4), np.uint64)
+        self.l.hc_hash_ds_level(h, mode, C.c_size_t(arity), C.c_uint32(level), C.c_uint64(pos0), C.c_uint64(label), P(in0), P(None if in1 is None else A(in1)), C.c_size_t(n_in), P(out)); return out
+
+    def tr_hash(self, h, tag: bytes, fields, n=1):
+        f = A(fields); k = (f.shape[0] // n) if f.size else 0; out = np.zeros((n, 4), np.uint64)
+        self.l.hc_tr_hash(h, tag, P(f), C.c_size_t(k), C.c_size_t(n), P(out)); return out[0] if n == 1 else out
+
+    def hash_stream(self, h, mode, a, na, b, nb, tag=None, n=1):
+        out = np.zeros((n, 4), np.uint64)
+        self.l.hc_hash_stream(h, mode, P(A(a)) if na else None, C.c_size_t(na), P(A(b)) if nb else None, C.c_size_t(nb), P(None if tag is None else A(tag)), C.c_size_t(n), P(out))
+        return out[0] if n == 1 else out

@@ -1,0 +1,285 @@
+"""Parity tests proper: the HIP path through the C-ABI against the oracle on identical seeded inputs
+(bit-exact: everything here is exact integer arithmetic), plus size-independent properties at the
+BASELINE sizes.  Needs an MI355X: `pytest -m gpu`."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from stark_mlwe_amd.api import BLS12_381_FR, PALLAS_FR, DeepFriParams, StarkError
+
+
+def F(oracle, x):
+    return oracle.from_u64(x)
+
+
+# ---- Poseidon -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t", [9, 17, 33])
+def test_permute_batch(gpu_ctx, oracle, t):
+    n = 130 if t <= 17 else 70                      # not a multiple of the 64-lane workgroup
+    states = np.concatenate([oracle.synth_column(3, t, 0, (n - 1) * t), np.zeros((t, 4), np.uint64)]).reshape(n, t, 4)
+    got = gpu_ctx.permute(states, gpu_ctx.poseidon_params_for_width(t))
+    assert (got == oracle.permute(0, t, states)).all()
+
+
+def test_permute_t17_bench_params_zero_state(gpu_ctx, oracle):
+    # poseidon/benches/poseidon.rs:6-15: generate_params_t17_x5(b"POSEIDON-T17-X5"), state [0;17]
+    p = gpu_ctx.generate_params_t17_x5(b"POSEIDON-T17-X5")
+    z = np.zeros((1, 17, 4), np.uint64)
+    assert (gpu_ctx.permute(z, p) == oracle.permute(3, 17, z)).all()
+    mds, rcf, rcp = p.export()
+    _, _, m2, f2, p2 = oracle.poseidon_params(3, 17)
+    assert (mds == m2).all() and (rcf == f2).all() and (rcp == p2).all()
+    p.free()
+
+
+def test_params_upload_roundtrip(gpu_ctx, oracle):
+    rf, rp, mds, rcf, rcp = oracle.poseidon_params(0, 9)
+    p = gpu_ctx.params_upload(9, rf, rp, mds, rcf, rcp)
+    st = oracle.synth_column(1, 1, 0, 18).reshape(2, 9, 4)
+    assert (gpu_ctx.permute(st, p) == oracle.permute(0, 9, st)).all()
+    p.free()
+    with pytest.raises(StarkError):
+        gpu_ctx.poseidon_params_for_width(10)          # unsupported width (poseidon/src/lib.rs:127 panics)
+
+
+def test_hash_with_ds_dynamic_reference_shapes(gpu_ctx, oracle):
+    # merkle/src/lib.rs:966-1050 (t=17: 16 / 5 / 5+zero children; t=9: 8 / 3 / 3+zero)
+    p17, p9 = gpu_ctx.poseidon_params_for_width(17), gpu_ctx.poseidon_params_for_width(9)
+    ds = np.array([F(oracle, x) for x in (16, 0, 3, 42)])
+    digs = []
+    for ch in (list(range(1, 17)), list(range(1, 6)), list(range(1, 6)) + [0]):
+        c = np.array([F(oracle, x) for x in ch])
+        got = gpu_ctx.hash_with_ds_dynamic(ds, c, p17)
+        assert (got == oracle.hash_with_ds_dynamic(0, 17, ds, c, len(ch))).all()
+        digs.append(got.tobytes())
+    assert len(set(digs)) == 3
+    ds9 = np.array([F(oracle, x) for x in (8, 2, 5, 7)])
+    for ch in (list(range(11, 19)), [21, 22, 23], [21, 22, 23, 0]):
+        c = np.array([F(oracle, x) for x in ch])
+        assert (gpu_ctx.hash_with_ds_dynamic(ds9, c, p9) == oracle.hash_with_ds_dynamic(0, 9, ds9, c, len(ch))).all()
+    # legacy sponge (poseidon/src/lib.rs:85-100) with the commitment seed
+    ps = gpu_ctx.generate_params_t17_x5(b"POSEIDON-T17-X5-SEED")
+    for cnt in (0, 2, 16, 37):
+        c = oracle.synth_column(9, 9, 0, cnt) if cnt else np.zeros((0, 4), np.uint64)
+        assert (gpu_ctx.hash_with_ds(c, F(oracle, 77), ps) == oracle.hash_with_ds(2, c, F(oracle, 77))).all()
+    ps.free()
+
+
+def test_leaf_pair_hash_layer(gpu_ctx, oracle):
+    n, m = 1 << 12, 16
+    f, fn = oracle.synth_column(5, 0, 0, n), oracle.synth_column(5, 1, 0, n // m)
+    assert (gpu_ctx.leaf_pair_hash(f, fn, m) == oracle.leaf_pair_hash(f, fn, m)).all()
+    assert (gpu_ctx.leaf_pair_hash(f[:100], None, 1) == oracle.leaf_pair_hash(f[:100], None, 1)).all()      # last layer: s = 0
+    assert (gpu_ctx.hash_leaf_pair(F(oracle, 1), F(oracle, 2)) == oracle.leaf_pair_hash(F(oracle, 1).reshape(1, 4), F(oracle, 2).reshape(1, 4), 1)[0]).all()
+    assert gpu_ctx.leaf_pair_hash(np.zeros((0, 4), np.uint64), None, 1).shape == (0, 4)                     # empty input
+
+
+def test_tr_hash_fields_tagged(gpu_ctx, oracle):
+    for n in (0, 1, 5, 12, 13, 29, 200):
+        xs = oracle.synth_column(6, 0, 0, n) if n else np.zeros((0, 4), np.uint64)
+        assert (gpu_ctx.tr_hash_fields_tagged(b"ALI/A", xs) == oracle.tr_hash_fields_tagged(b"ALI/A", xs)).all()
+    batch = oracle.synth_column(6, 1, 0, 300)
+    got = gpu_ctx.tr_hash_fields_tagged(b"FRI/index", batch, n=100)
+    for i in (0, 1, 63, 64, 99):
+        assert (got[i] == oracle.tr_hash_fields_tagged(b"FRI/index", batch[3 * i:3 * i + 3])).all()
+
+
+# ---- Merkle ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arity,n,label", [(16, 4096, 0), (16, 55, 9), (16, 64, 42), (8, 512, 2), (8, 19, 3), (2, 8, 1), (4, 64, 7), (16, 1, 5), (32, 1024, 4)])
+def test_merkle_tree_levels(gpu_ctx, oracle, arity, n, label):
+    leaves = oracle.synth_column(4, 3, 0, n)
+    t = gpu_ctx.merkle_new(leaves, gpu_ctx.merkle_cfg(arity, label))
+    o = oracle.merkle_build(arity, label, leaves)
+    assert t.num_levels == o.num_levels()
+    for lvl in range(t.num_levels):
+        assert (t.level(lvl) == o.level(lvl)).all(), lvl
+    assert (t.root() == o.root()).all()
+    t.free(); o.free()
+
+
+@pytest.mark.parametrize("arity,n", [(2, 8), (2, 2), (16, 64), (8, 32), (2, 1)])
+def test_merkle_pairs(gpu_ctx, oracle, arity, n):
+    f, cp = oracle.synth_column(4, 0, 0, n), oracle.synth_column(4, 1, 0, n)
+    t = gpu_ctx.merkle_new_pairs(f, cp, gpu_ctx.merkle_cfg(arity, 777))
+    o = oracle.merkle_build(arity, 777, f, cp)
+    for lvl in range(o.num_levels()):
+        assert (t.level(lvl) == o.level(lvl)).all()
+    t.free(); o.free()
+
+
+def test_merkle_errors_and_open(gpu_ctx, oracle):
+    with pytest.raises(StarkError):
+        gpu_ctx.merkle_new(np.zeros((0, 4), np.uint64), gpu_ctx.merkle_cfg(16))                     # "no leaves"
+    from stark_mlwe_amd.api import MerkleChannelCfg
+    with pytest.raises(StarkError):
+        gpu_ctx.merkle_new(oracle.synth_column(1, 1, 0, 16), MerkleChannelCfg(16, gpu_ctx.poseidon_params_for_width(9)))   # arity/width mismatch
+    # open_union_of_paths: reference test indices (merkle/src/lib.rs:948); decode the canonical proof and
+    # check every sibling against the tree levels, and the sibling count against the oracle's own opening
+    leaves = oracle.rand_fr_columns(999, 64)[0]
+    t = gpu_ctx.merkle_new(leaves, gpu_ctx.merkle_cfg(16, 42))
+    o = oracle.merkle_build(16, 42, leaves)
+    idx = [63, 0, 15, 16, 31, 47, 15]
+    b = t.open_many(idx)
+    u = lambda off: struct.unpack_from("<Q", b, off)[0]
+    off = 0; k = u(off); off += 8
+    indices = [u(off + 8 * i) for i in range(k)]; off += 8 * k
+    assert indices == sorted(set(idx))
+    nlev = u(off); off += 8
+    sib_total = 0; sibs = []
+    for _ in range(nlev):
+        c = u(off); off += 8; sibs.append([b[off + 32 * i: off + 32 * i + 32] for i in range(c)]); off += 32 * c; sib_total += c
+    ok, nsib = o.open_verify(idx, leaves[idx])
+    assert ok == 1 and nsib == sib_total
+    cur = indices
+    for lvl in range(nlev):
+        level = t.level(lvl); want = []
+        for p in sorted(set(i // 16 for i in cur)):
+            want += [oracle.to_bytes_le(level[c]) for c in range(16 * p, min(16 * p + 16, len(level))) if c not in cur]
+        assert sibs[lvl] == want
+        cur = sorted(set(i // 16 for i in cur))
+    ng = u(off); off += 8
+    for _ in range(ng):
+        c = u(off); off += 8 + c
+    assert u(off) == 16 and off + 8 == len(b)
+    t.free(); o.free()
+
+
+# ---- FRI -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [2, 4, 8, 16, 32, 64, 128, 3, 6])
+def test_fri_fold_layer(gpu_ctx, oracle, m):
+    n = m * 37 if m in (3, 6) else max(m * 5, 1 << 11)
+    f = oracle.synth_column(2, 0, 0, n); z = oracle.fri_sample_z_ell(0xDEEFBAAD, 0, 1 << 11)
+    got = gpu_ctx.fri_fold_layer(f, z, m)
+    assert (got == oracle.fri_fold_layer(f, z, m)).all()
+    assert (gpu_ctx.compute_s_layer(f, z, m) == oracle.compute_s_layer(f, z, m)).all()
+
+
+def test_fri_fold_reference_vector_and_errors(gpu_ctx, oracle):
+    f = np.array([F(oracle, x) for x in range(1, 65)]); z = F(oracle, 3)
+    assert (gpu_ctx.fri_fold_layer(f, z, 16) == oracle.fri_fold_layer(f, z, 16)).all()
+    with pytest.raises(StarkError): gpu_ctx.fri_fold_layer(f, z, 1)           # assert!(m >= 2), fri.rs:86
+    with pytest.raises(StarkError): gpu_ctx.fri_fold_layer(f, z, 5)           # fri.rs:87
+    assert gpu_ctx.fri_fold_layer(np.zeros((0, 4), np.uint64), z, 4).shape == (0, 4)
+
+
+def test_fri_sample_z(gpu_ctx, oracle):
+    for level, size in ((0, 1 << 12), (1, 1 << 8), (2, 16), (0, 1 << 20)):
+        assert (gpu_ctx.fri_sample_z_ell(0xDEEFBAAD, level, size) == oracle.fri_sample_z_ell(0xDEEFBAAD, level, size)).all()
+
+
+@pytest.mark.parametrize("n0,sched", [(1 << 12, [16, 16, 8]), (1 << 11, [16, 16, 8]), (1 << 10, [32, 32]), (1 << 9, [8, 4, 2]), (1 << 7, [128])])
+def test_fri_build_transcript(gpu_ctx, oracle, n0, sched):
+    f0 = oracle.synth_column(3, 0, 0, n0)
+    st = gpu_ctx.fri_build_transcript(f0, sched, 0xDEEFBAAD)
+    ref = oracle.deep_fri_prove(None, None, None, None, n0, sched, 1, 0xDEEFBAAD, f0=f0)
+    assert st.num_layers == len(sched) + 1
+    for l in range(st.num_layers):
+        assert (st.f_layer(l) == ref.layer_f(l)).all()
+        assert (st.root(l) == ref.root(l)).all(), l
+        if l < len(sched):
+            assert (st.z(l) == ref.z(l)).all()
+    st.free(); ref.free()
+
+
+# ---- DEEP-ALI / end-to-end -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 64, 1000, 1 << 12])
+def test_ali_merge(gpu_ctx, oracle, n):
+    cols = [oracle.synth_column(8, c, 0, n) for c in range(5)]
+    lg = max(1, (n - 1).bit_length())
+    omega, z, beta = oracle.root_of_unity(lg), F(oracle, 0xC0FFEE), F(oracle, 12345)
+    f0, _, cs = gpu_ctx.deep_ali_merge_evals(cols[0], cols[1], cols[2], cols[3], omega, z)
+    w0, wc = oracle.ali_merge(cols[0], cols[1], cols[2], cols[3], omega, z)
+    assert (f0 == w0).all()
+    if n == (1 << lg):
+        assert (cs == wc).all()            # c* is a statement about the full domain
+    f1, _, _ = gpu_ctx.deep_ali_merge_evals(cols[0], cols[1], cols[2], cols[3], omega, z, r_eval=cols[4], beta=beta, want_c_star=False)
+    w1, _ = oracle.ali_merge(cols[0], cols[1], cols[2], cols[3], omega, z, r=cols[4], beta=beta, want_c_star=False)
+    assert (f1 == w1).all()
+    with pytest.raises(StarkError):
+        gpu_ctx.deep_ali_merge_evals(cols[0], cols[1], cols[2], cols[3], omega, F(oracle, 1))       # z in H
+
+
+def test_build_f0(gpu_ctx, oracle):
+    n0 = 1 << 9
+    cols = oracle.rand_fr_columns(1337, n0, 4)
+    f0, aux = gpu_ctx.build_f0(cols[0], cols[1], cols[2], cols[3], n0)
+    w0, waux = oracle.build_f0(cols[0], cols[1], cols[2], cols[3], n0)
+    assert (aux == waux).all()             # column digests, seed_f, z, beta
+    assert (f0 == w0).all()
+
+
+@pytest.mark.parametrize("n0,sched,r", [(1 << 11, [16, 16, 8], 32), (1 << 10, [16, 8], 8), (1 << 9, [8, 4, 2], 5), (1 << 10, [32, 32], 40)])
+def test_deep_fri_prove_bytes(gpu_ctx, oracle, n0, sched, r):
+    cols = oracle.rand_fr_columns(4242 + n0, n0, 4)
+    got, est, _ = gpu_ctx.deep_fri_prove(cols[0], cols[1], cols[2], cols[3], n0, DeepFriParams(sched, r, 0xDEEFBAAD))
+    ref = oracle.deep_fri_prove(cols[0], cols[1], cols[2], cols[3], n0, sched, r, 0xDEEFBAAD)
+    assert got == ref.bytes()              # bit-exact proof bytes
+    assert est == ref.size_estimate()
+    assert oracle.deep_fri_verify(got, sched, r, 0xDEEFBAAD) == 1
+    ref.free()
+
+
+def test_published_fingerprint_k11_on_gpu(gpu_ctx, oracle):
+    """The reference's own bench input for k = 11 (end_to_end.rs:248-253) through the GPU prover:
+    deep_fri_proof_size_bytes must be the published 39592 (crates/channel/benchmarkdata.csv:2)."""
+    seed = (1337 * 1103515245 + 12345) % 2**64
+    cols = oracle.rand_fr_columns(seed, 1 << 11, 4)
+    got, est, _ = gpu_ctx.deep_fri_prove(cols[0], cols[1], cols[2], cols[3], 1 << 11, DeepFriParams([16, 16, 8], 32, 0xDEEFBAAD))
+    assert est == 39592
+    assert oracle.deep_fri_verify(got, [16, 16, 8], 32, 0xDEEFBAAD) == 1
+
+
+# ---- NTT -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("field", [PALLAS_FR, BLS12_381_FR])
+@pytest.mark.parametrize("lg", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 16])
+def test_ntt_vs_oracle(gpu_ctx, oracle, field, lg):
+    x = oracle.synth_column(77, 7, 0, 1 << lg)
+    y = gpu_ctx.fft(x, field=field)
+    assert (y == oracle.ntt(field, x)).all()
+    assert (gpu_ctx.ifft(y, field=field) == x).all()
+    assert (gpu_ctx.ifft(x, field=field) == oracle.ntt(field, x, inverse=True)).all()
+
+
+@pytest.mark.parametrize("field,gen", [(PALLAS_FR, 5), (BLS12_381_FR, 7)])
+def test_ntt_coset_lde_and_reference_roundtrip(gpu_ctx, oracle, field, gen):
+    g = oracle.from_u64(gen, field)
+    for lg in (3, 10, 12):
+        x = oracle.synth_column(78, 7, 0, 1 << lg)
+        y = gpu_ctx.fft(x, field=field, coset=g)
+        assert (y == oracle.ntt(field, x, coset=g)).all()
+        assert (gpu_ctx.ifft(y, field=field, coset=g) == x).all()
+    ev = oracle.synth_column(79, 0, 0, 1 << 9)
+    assert (gpu_ctx.lde(ev, 3, field=field, coset=g) == oracle.lde(field, ev, 3, g)).all()
+    assert (gpu_ctx.lde(ev, 3, field=field)[::8] == ev).all()
+    ones = np.tile(oracle.from_u64(1, field), (8, 1))                      # fft/src/lib.rs:39-54
+    assert (gpu_ctx.ifft(gpu_ctx.fft(ones, field=field), field=field) == ones).all()
+    with pytest.raises(StarkError):
+        gpu_ctx.fft(ones[:6], field=field)
+
+
+@pytest.mark.parametrize("lg", [20, 21])
+def test_ntt_large_vs_oracle_and_properties(gpu_ctx, oracle, lg):
+    """BASELINE size 2^20 (and a 3-pass size) against the oracle's radix-2 NTT, plus linearity."""
+    x = oracle.synth_column(80, 7, 0, 1 << lg)
+    y = gpu_ctx.fft(x, field=PALLAS_FR)
+    assert (y == oracle.ntt(0, x)).all()
+    assert (gpu_ctx.ifft(y, field=PALLAS_FR) == x).all()
+    # the DC term is the sum of the inputs; a shifted delta transforms to the powers of w
+    d = np.zeros((1 << lg, 4), np.uint64); d[1] = oracle.from_u64(1)
+    yd = gpu_ctx.fft(d, field=PALLAS_FR)
+    w = oracle.root_of_unity(lg)
+    assert (yd[0] == oracle.from_u64(1)).all() and (yd[1] == w).all() and (yd[2] == oracle.mul(w, w)).all()
+
+
+def test_synthetic_generator(gpu_ctx, oracle):
+    import ctypes as C
+    import torch
+    n = 1000
+    buf = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, 0x5EED0014, 2, 12345, n, C.c_void_p(buf.data_ptr())))
+    gpu_ctx.sync()
+    got = buf.cpu().numpy().view(np.uint64)
+    assert (got == oracle.synth_column(0x5EED0014, 2, 12345, n)).all()

@@ -1,0 +1,114 @@
+"""Product host logic and kernel BODIES (host build of the same inline code, libstark_mlwe_hostcheck.so)
+against the oracle.  CPU only; this is a diagnostic library — no product path calls it."""
+import random
+
+import numpy as np
+import pytest
+
+import pyref
+
+
+@pytest.mark.parametrize("field,p", [(0, pyref.P_PALLAS), (1, pyref.P_BLS)])
+def test_fr_hpp_vs_oracle(oracle, hostcheck, field, p):
+    rng = random.Random(99 + field)
+    vals = [0, 1, 2, p - 1, p - 2, (1 << 254) % p, (1 << 255) % p] + [rng.randrange(p) for _ in range(60)]
+    for x in vals:
+        for y in (vals[rng.randrange(len(vals))], vals[rng.randrange(len(vals))]):
+            a, b = oracle.from_int(x, field), oracle.from_int(y, field)
+            for op in (0, 1, 2):
+                assert (hostcheck.fr_op(field, op, a, b) == oracle.fr_op(field, op, a, b)).all(), (op, x, y)
+    for x in (1, 5, p - 1, rng.randrange(p)):
+        a = oracle.from_int(x, field)
+        assert (hostcheck.fr_op(field, 3, a) == oracle.inv(a, field)).all()
+        assert (hostcheck.fr_op(field, 5, a) == oracle.to_canonical(a, field)).all()
+        assert (hostcheck.fr_op(field, 7, a, np.array([12345, 0, 0, 0], np.uint64)) == oracle.pow(a, 12345, field)).all()
+    for u in (0, 1, 2**32, 2**64 - 1):
+        assert (hostcheck.fr_op(field, 4, np.array([u, 0, 0, 0], np.uint64)) == oracle.from_u64(u, field)).all()
+    for lg in (1, 11, 20, 32):
+        assert (hostcheck.fr_op(field, 6, np.array([lg, 0, 0, 0], np.uint64)) == oracle.root_of_unity(lg, field)).all()
+
+
+def test_host_bytes_helpers(oracle, hostcheck):
+    rng = random.Random(3)
+    for n in (1, 20, 31, 32, 33, 64):
+        b = bytes(rng.randrange(256) for _ in range(n))
+        assert (hostcheck.from_le_bytes_mod_order(b) == oracle.from_le_bytes_mod_order(b)).all()
+    a = oracle.from_int(rng.randrange(pyref.P_PALLAS))
+    assert hostcheck.to_bytes_le(a) == oracle.to_bytes_le(a)
+
+
+@pytest.mark.parametrize("kind,t,seed,okind", [(0, 9, b"", 0), (0, 17, b"", 0), (1, 17, b"", 1), (2, 17, b"POSEIDON-T17-X5-SEED", 2), (2, 17, b"POSEIDON-T17-X5", 3), (0, 33, b"", 0)])
+def test_constants_and_kernel_form_permutation(oracle, hostcheck, kind, t, seed, okind):
+    h = hostcheck.params(kind, t, seed)
+    assert hostcheck.params_ok(h) == 1
+    rf, rp, mds, rcf, rcp = oracle.poseidon_params(okind, t)
+    m2, f2, p2 = hostcheck.params_export(h, t, rf, rp)
+    assert (m2 == mds).all() and (f2 == rcf).all() and (p2 == rcp).all()
+    n = 3 if t > 17 else 6
+    states = np.concatenate([oracle.synth_column(11, 2, 0, (n - 1) * t), np.zeros((t, 4), np.uint64)]).reshape(n, t, 4)
+    want = oracle.permute(okind, t, states)
+    assert (hostcheck.permute_dense(h, states, t) == want).all()
+    assert (hostcheck.permute_kernel_form(h, states, t) == want).all()      # LU + sparse partial rounds == dense rounds, bit for bit
+    hostcheck.params_free(h)
+
+
+def test_leaf_pair_body(oracle, hostcheck):
+    h = hostcheck.params(1)
+    f = oracle.synth_column(1, 0, 0, 40); fn = oracle.synth_column(1, 1, 0, 5)
+    assert (hostcheck.leaf_pair(h, f, fn, 8) == oracle.leaf_pair_hash(f, fn, 8)).all()
+    assert (hostcheck.leaf_pair(h, f[:7], None, 1) == oracle.leaf_pair_hash(f[:7], None, 1)).all()
+    hostcheck.params_free(h)
+
+
+@pytest.mark.parametrize("arity,n", [(16, 64), (16, 55), (8, 24), (8, 19), (2, 6), (4, 16), (16, 16), (16, 11)])
+def test_hash_ds_body_builds_oracle_tree(oracle, hostcheck, arity, n):
+    t = 9 if arity <= 8 else 17
+    h = hostcheck.params(0, t)
+    leaves = oracle.synth_column(4, 3, 0, n)
+    tree = oracle.merkle_build(arity, 77, leaves)
+    cur, level = leaves, 0
+    while cur.shape[0] > 1:
+        cur = hostcheck.hash_ds_level(h, 0, arity, level, 0, 77, cur)
+        level += 1
+        assert (cur == tree.level(level)).all()
+    tree.free()
+    # pair-leaf level (merkle/src/lib.rs:380-388)
+    cp = oracle.synth_column(4, 4, 0, n)
+    ptree = oracle.merkle_build(arity, 5, leaves, cp)
+    assert (hostcheck.hash_ds_level(h, 1, arity, 0xFFFFFFFF, 0, 5, leaves, cp) == ptree.level(0)).all()
+    ptree.free(); hostcheck.params_free(h)
+
+
+def test_sharded_level_positions(oracle, hostcheck):
+    # a shard hashing parents [pos0, pos0+k) of a larger level gets the same digests (global DS positions)
+    h = hostcheck.params(0, 17)
+    leaves = oracle.synth_column(8, 0, 0, 256)
+    whole = hostcheck.hash_ds_level(h, 0, 16, 0, 0, 3, leaves)
+    part = hostcheck.hash_ds_level(h, 0, 16, 0, 8, 3, leaves[128:])
+    assert (part == whole[8:]).all()
+    hostcheck.params_free(h)
+
+
+def test_tr_hash_body(oracle, hostcheck):
+    h = hostcheck.params(1)
+    for n in (0, 1, 3, 12, 13, 28, 29, 45):
+        xs = oracle.synth_column(6, 0, 0, n) if n else np.zeros((0, 4), np.uint64)
+        assert (hostcheck.tr_hash(h, b"ALI/A", xs) == oracle.tr_hash_fields_tagged(b"ALI/A", xs)).all(), n
+    batch = oracle.synth_column(6, 1, 0, 15)
+    got = hostcheck.tr_hash(h, b"FRI/index", batch, n=5)
+    for i in range(5):
+        assert (got[i] == oracle.tr_hash_fields_tagged(b"FRI/index", batch[3 * i:3 * i + 3])).all()
+    hostcheck.params_free(h)
+
+
+def test_hash_stream_body(oracle, hostcheck):
+    h17, hseed = hostcheck.params(0, 17), hostcheck.params(2, 17, b"POSEIDON-T17-X5-SEED")
+    ds = np.array([oracle.from_u64(x) for x in (16, 0, 3, 42)])
+    for cnt in (0, 5, 11, 12, 16, 27, 28):
+        ch = oracle.synth_column(2, 0, 0, cnt) if cnt else np.zeros((0, 4), np.uint64)
+        assert (hostcheck.hash_stream(h17, 0, ds, 4, ch, cnt) == oracle.hash_with_ds_dynamic(0, 17, ds, ch, cnt)).all(), cnt
+    tag = oracle.from_u64(77)
+    for cnt in (0, 1, 2, 16, 17, 37):
+        ch = oracle.synth_column(2, 1, 0, cnt) if cnt else np.zeros((0, 4), np.uint64)
+        assert (hostcheck.hash_stream(hseed, 1, None, 0, ch, cnt, tag) == oracle.hash_with_ds(2, ch, tag)).all(), cnt
+    hostcheck.params_free(h17); hostcheck.params_free(hseed)
