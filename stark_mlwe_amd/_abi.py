@@ -100,6 +100,14 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HIP runtimes in
+    # one process cannot both own the GPU, so when torch is part of the process (bench.py, tests) it must
+    # be loaded FIRST: the dynamic loader then binds this library's libamdhip64.so.7 dependency to the
+    # copy torch already mapped (same SONAME) and both share device memory, streams and events.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # a host without torch uses the system ROCm runtime
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(
