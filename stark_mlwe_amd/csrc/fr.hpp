@@ -107,10 +107,10 @@ template <class F> FR_HD fr_t fr_sub(const fr_t& a, const fr_t& b) {
 }
 template <class F> FR_HD fr_t fr_neg(const fr_t& a) { return fr_sub<F>(fr_zero<F>(), a); }
 
-// Montgomery product, word-serial CIOS over 32-bit limbs.  NINV == 0xffffffff for both fields
-// (r == 1 mod 2^32), so m = -t0 needs no multiply; the m*P(j) terms with P(j) in {0, 1, 2^30}
-// fold to nothing / an add / a shift at compile time (Pallas: limbs 4..6 are zero).
-template <class F> FR_HD fr_t fr_mul(const fr_t& a, const fr_t& b) {
+// Montgomery product, word-serial CIOS over 32-bit limbs (portable C++: host build and reference for
+// the device path).  NINV == 0xffffffff for both fields (r == 1 mod 2^32), so m = -t0 needs no
+// multiply; the m*P(j) terms with P(j) in {0, 1, 2^30} fold away at compile time.
+template <class F> FR_HD fr_t fr_mul_portable(const fr_t& a, const fr_t& b) {
     uint32_t t[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) t[i] = 0;
@@ -132,6 +132,86 @@ template <class F> FR_HD fr_t fr_mul(const fr_t& a, const fr_t& b) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) z.v[i] = t[i];
     return z;
+}
+
+// ---- sums of products with ONE Montgomery reduction ("wide" accumulator) ----------------------------------
+// 15 independent 96-bit column accumulators {hi : ml}; W += a*b adds the 64 partial products of one
+// term, fr_wide_reduce folds in the Montgomery quotient terms and returns the fully reduced element.
+// Inputs must be reduced (< r); at most 32 terms per accumulator.  Used for the MDS / sparse-matrix
+// dot products of the Poseidon rounds: per extra term only the 64 MACs are paid, not the reduction.
+struct fr_wide { uint64_t ml[15]; uint32_t hi[15]; };
+FR_HD void fr_wide_zero(fr_wide& w) {
+#pragma unroll
+    for (int c = 0; c < 15; ++c) { w.ml[c] = 0; w.hi[c] = 0; }
+}
+// t[0..8] < 16 r  ->  t[0..7] in [0, r): conditional subtraction of 8r, 4r, 2r, r.
+template <class F> FR_HD void fr_reduce_wide_tail(uint32_t* t) {
+#pragma unroll
+    for (int s = 3; s >= 0; --s) {
+        uint32_t d[9]; uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const uint32_t lo = i < 8 ? F::P(i) : 0u, below = i > 0 ? F::P(i - 1) : 0u;
+            const uint32_t ps = s == 0 ? lo : ((lo << s) | (below >> (32 - s)));      // limb i of (r << s)
+            uint64_t x = (uint64_t)t[i] - ps - br; d[i] = (uint32_t)x; br = (x >> 32) & 1;
+        }
+        const bool take = br == 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t[i] = take ? d[i] : t[i];
+    }
+}
+template <class F> FR_HD void fr_wide_mac_portable(fr_wide& w, const fr_t& a, const fr_t& b) {
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) { uint64_t pr = (uint64_t)a.v[i] * b.v[j]; uint64_t x = w.ml[i + j] + pr; w.hi[i + j] += x < pr ? 1u : 0u; w.ml[i + j] = x; }
+}
+template <class F> FR_HD fr_t fr_wide_reduce_portable(const fr_wide& w) {
+    uint64_t ml = 0; uint32_t hi = 0; uint32_t m[8]; uint32_t t[9];
+    for (int c = 0; c < 15; ++c) {
+        { uint64_t x = ml + w.ml[c]; hi += w.hi[c] + (x < ml ? 1u : 0u); ml = x; }
+        for (int k = (c > 7 ? c - 7 : 0); k <= (c - 1 < 7 ? c - 1 : 7); ++k) {
+            const uint32_t pj = F::P(c - k);
+            if (pj) { uint64_t pr = (uint64_t)m[k] * pj; uint64_t x = ml + pr; hi += x < pr ? 1u : 0u; ml = x; }
+        }
+        const uint32_t lo = (uint32_t)ml;
+        if (c < 8) { m[c] = 0u - lo; ml = ((ml >> 32) | ((uint64_t)hi << 32)) + (lo != 0u ? 1u : 0u); hi = 0; }
+        else { t[c - 8] = lo; ml = (ml >> 32) | ((uint64_t)hi << 32); hi = 0; }
+    }
+    t[7] = (uint32_t)ml; t[8] = (uint32_t)(ml >> 32);
+    fr_reduce_wide_tail<F>(t);
+    fr_t z; for (int i = 0; i < 8; ++i) z.v[i] = t[i]; return z;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 device path (generated: tools/gen_fr_gfx950.py).  Every 32x32 partial product costs exactly
+//     v_mad_u64_u32  ml, vcc, x, y, ml      (32x32+64 MAC, ~4 cycles per wave64 on CDNA4)
+//     v_addc_co_u32  hi, vcc, 0, hi, vcc    (carry count)
+// with no zero-extension moves (the portable form costs ~7 VALU instructions per product after
+// instruction selection).  The Montgomery quotient digits m_c = -lo(column c) are free because
+// r == 1 (mod 2^32); limbs of r that are zero contribute nothing (Pallas: 3 of 8).
+template <class F> __device__ __forceinline__ fr_t fr_mul_dev(const fr_t& a, const fr_t& b);
+template <class F> __device__ __forceinline__ fr_t fr_wide_reduce_dev(const fr_wide& w);
+#include "fr_gfx950.inc"
+#endif
+template <class F> FR_HD fr_t fr_mul(const fr_t& a, const fr_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fr_mul_dev<F>(a, b);
+#else
+    return fr_mul_portable<F>(a, b);
+#endif
+}
+template <class F> FR_HD fr_t fr_wide_reduce(const fr_wide& w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fr_wide_reduce_dev<F>(w);
+#else
+    return fr_wide_reduce_portable<F>(w);
+#endif
+}
+template <class F> FR_HD void fr_wide_mac_f(fr_wide& w, const fr_t& a, const fr_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    fr_wide_mac(w, a, b);
+#else
+    fr_wide_mac_portable<F>(w, a, b);
+#endif
 }
 template <class F> FR_HD fr_t fr_sqr(const fr_t& a) { return fr_mul<F>(a, a); }
 template <class F> FR_HD fr_t fr_pow5(const fr_t& x) {   // S-box x^5 = x * (x^2)^2  (poseidon/src/lib.rs:24-29)

@@ -34,16 +34,18 @@ struct ArrayState {
 };
 
 // y = L*(U*x) in place.  U: row i needs x[j>=i] (top-down); unit-lower L: row i needs y[j<i] (bottom-up).
+// Every row is a dot product with wave-uniform constants: the 64-MAC partial products of all its terms
+// are summed in one wide accumulator and reduced once (fr.hpp "wide").
 template <class S> FR_HD void apply_lu(const S& s, const fr_t* lu, int t) {
     for (int i = 0; i < t; ++i) {
-        fr_t acc = fr_mul<PF>(lu[i * t + i], s.ld(i));
-        for (int j = i + 1; j < t; ++j) acc = fr_add<PF>(acc, fr_mul<PF>(lu[i * t + j], s.ld(j)));
-        s.st(i, acc);
+        fr_wide w; fr_wide_zero(w);
+        for (int j = i; j < t; ++j) fr_wide_mac_f<PF>(w, lu[i * t + j], s.ld(j));
+        s.st(i, fr_wide_reduce<PF>(w));
     }
     for (int i = t - 1; i >= 1; --i) {
-        fr_t acc = s.ld(i);
-        for (int j = 0; j < i; ++j) acc = fr_add<PF>(acc, fr_mul<PF>(lu[i * t + j], s.ld(j)));
-        s.st(i, acc);
+        fr_wide w; fr_wide_zero(w);
+        for (int j = 0; j < i; ++j) fr_wide_mac_f<PF>(w, lu[i * t + j], s.ld(j));
+        s.st(i, fr_add<PF>(s.ld(i), fr_wide_reduce<PF>(w)));
     }
 }
 // One Poseidon permutation of the state behind `s`.  Returns lane 0 of the result.  With `only0`
@@ -59,21 +61,22 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
     for (int r = 0; r < P.rp; ++r) {
         const fr_t* sp = P.sparse + (size_t)r * w;
         s0 = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[r]));
-        fr_t acc = fr_mul<PF>(sp[0], s0);
+        fr_wide acc; fr_wide_zero(acc);
+        fr_wide_mac_f<PF>(acc, sp[0], s0);                         // s0' = a*s0 + sum_j u_j*s_j   (one reduction)
         for (int j = 1; j < t; ++j) {
             fr_t sj = s.ld(j);
-            acc = fr_add<PF>(acc, fr_mul<PF>(sp[j], sj));
-            s.st(j, fr_add<PF>(sj, fr_mul<PF>(sp[t - 1 + j], s0)));
+            fr_wide_mac_f<PF>(acc, sp[j], sj);
+            s.st(j, fr_add<PF>(sj, fr_mul<PF>(sp[t - 1 + j], s0)));  // s_j' = s_j + w_j*s0 (old s0)
         }
-        s0 = acc;
+        s0 = fr_wide_reduce<PF>(acc);
     }
     s.st(0, s0);
     for (int r = half; r < P.rf; ++r) {
         for (int j = 0; j < t; ++j) s.st(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));
         if (only0 && r == P.rf - 1) {
-            fr_t acc = fr_mul<PF>(P.row0[0], s.ld(0));
-            for (int j = 1; j < t; ++j) acc = fr_add<PF>(acc, fr_mul<PF>(P.row0[j], s.ld(j)));
-            return acc;
+            fr_wide acc; fr_wide_zero(acc);
+            for (int j = 0; j < t; ++j) fr_wide_mac_f<PF>(acc, P.row0[j], s.ld(j));
+            return fr_wide_reduce<PF>(acc);
         }
         apply_lu(s, P.lu, t);
     }
