@@ -202,7 +202,7 @@ def cpu_baseline(np, log_n_gpu):
     t0 = time.perf_counter()
     ext = [o.lde(0, c, LOG_BLOWUP, coset) for c in cols]
     f0, _ = o.ali_merge(ext[0], ext[1], ext[2], ext[3], omega, z, want_c_star=False)
-    pr = o.deep_fri_prove(None, None, None, None, N, SCHEDULE, 0, SEED_Z, f0=f0)
+    pr = o.deep_fri_prove(None, None, None, None, N, SCHEDULE, 1, SEED_Z, f0=f0)   # r = 1: the reference panics on an empty query set
     dt = time.perf_counter() - t0
     pr.free()
     return {"value": n / dt, "unit": "trace rows/s", "cores": 1, "kind": "port",

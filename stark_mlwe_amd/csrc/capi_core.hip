@@ -2,10 +2,12 @@
 // C-ABI declared in include/stark_mlwe.h.  No CPU compute fallback anywhere in this file: every
 // bulk operation is a kernel launch on the context's stream.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include "ctx.hpp"
 #include "poseidon_dev.hpp"
+#include "poseidon_pair.hpp"
 #include "fri_dev.hpp"
 
 using namespace stark;
@@ -13,6 +15,8 @@ using namespace stark;
 static const size_t kMaxLds = 160 * 1024;
 static inline int poseidon_block(int t) { return (size_t)t * 32 * 64 <= kMaxLds ? 64 : 32; }
 static inline size_t poseidon_lds(int t, int block) { return (size_t)t * 32 * block; }
+// the wave-pair kernels (poseidon_pair.hpp) serve the hot widths; STARK_POSEIDON_IMPL=lane selects the one-lane-per-sponge form
+static inline bool use_pair(int t) { static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }(); return !lane_only && t <= 17; }
 
 namespace stark {
 
@@ -133,6 +137,8 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     (void)hipFuncSetAttribute((const void*)k_permute_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_tr_hash, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_hash_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_leaf_pair2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_hash_ds2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     *out = c; return STARK_OK;
 }
 int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
@@ -233,6 +239,10 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, stark_params_t* p, int mode, siz
     DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
     J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
     if (!J.n_out) return STARK_OK;
+    if (use_pair(p->dev.t)) {
+        hipLaunchKernelGGL(k_hash_ds2, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(p->dev.t), ctx->stream, p->dev, J, in0, in1, out);
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
     const int block = poseidon_block(p->dev.t);
     hipLaunchKernelGGL(k_hash_ds, dim3((unsigned)((J.n_out + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), ctx->stream, p->dev, J, in0, in1, out);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
@@ -255,6 +265,10 @@ int32_t stark_leaf_pair_hash_dev(stark_ctx_t* ctx, stark_params_t* tp, const uin
     if (tp->dev.t != 17) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf hash uses the t=17 transcript permutation");
     if (!n) return STARK_OK;
     fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
+    if (use_pair(17)) {
+        hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), ctx->stream, tp->dev, init, as_fr(f), as_fr(f_next), n, m, as_fr(h));
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
     const int block = 64;
     hipLaunchKernelGGL(k_leaf_pair, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(17, block), ctx->stream, tp->dev, init, as_fr(f), as_fr(f_next), n, m, as_fr(h));
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
