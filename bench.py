@@ -191,10 +191,10 @@ def cpu_baseline(np, log_n_gpu):
     """The oracle (CPU port of the reference's algorithm) on a bounded sample of the same workload:
     a 2^10-row trace (LDE to 2^13, merge, FRI build).  Single thread, like the reference."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["OMP_NUM_THREADS"] = "1"
     import oracle_lib
     o = oracle_lib.Oracle()
-    lg = 10
+    o.l.oracle_set_threads(1)        # single thread, like the reference (no rayon in its dependency tree)
+    lg = 11
     n, N = 1 << lg, 1 << (lg + LOG_BLOWUP)
     seed = 0x5EED0000 + lg
     cols = [o.synth_column(seed, c, 0, n) for c in range(4)]

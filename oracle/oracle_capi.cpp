@@ -4,6 +4,7 @@
 // cpu_baseline leg).  The product library (stark_mlwe_amd/csrc) never links or loads this file.
 // Field elements cross this boundary as 4 little-endian u64 limbs in Montgomery form (ark-ff layout).
 #include <chrono>
+#include <omp.h>
 #include <cstdio>
 #include <stdexcept>
 #include "fri.hpp"
@@ -62,6 +63,8 @@ static const PoseidonParams& params_by_kind(int kind, int t) {
 #define CATCH } catch (const std::string& e) { fprintf(stderr, "oracle: %s\n", e.c_str()); return -1; } catch (...) { return -2; } return 0;
 
 extern "C" {
+
+int oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); return 0; }
 
 // ---- field ----------------------------------------------------------------------------------------
 int oracle_fr_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
