@@ -283,3 +283,37 @@ def test_synthetic_generator(gpu_ctx, oracle):
     gpu_ctx.sync()
     got = buf.cpu().numpy().view(np.uint64)
     assert (got == oracle.synth_column(0x5EED0014, 2, 12345, n)).all()
+
+
+# ---- multi-GPU building blocks on one GPU (world size 1: the exchange is the identity) -------------------------
+@pytest.mark.parametrize("log_n,log_rows,inverse", [(12, 6, False), (16, 8, False), (20, 10, False), (14, 7, True), (21, 10, False)])
+def test_six_step_building_blocks(gpu_ctx, oracle, log_n, log_rows, inverse):
+    import torch
+    from stark_mlwe_amd import dist as sd
+    n = 1 << log_n
+    x = oracle.synth_column(91, 7, 0, n)
+    plan = sd.DistNtt(sd.HipProvider(gpu_ctx), log_n, log_rows, inverse=inverse)
+    slab = torch.from_numpy(x[plan.local_input_indices().reshape(-1).numpy()].view(np.int64).copy()).cuda()
+    scale = oracle.inv(oracle.from_u64(n)) if inverse else None
+    rows = plan.forward(slab, scale)
+    gpu_ctx.sync()
+    want = oracle.ntt(0, x, inverse=inverse)
+    got = rows.cpu().numpy().view(np.uint64)
+    assert (got == want[plan.local_output_indices().reshape(-1).numpy()]).all()
+    nat = plan.to_natural_blocks(rows).cpu().numpy().view(np.uint64)
+    assert (nat == want).all()
+
+
+def test_sharded_merkle_single_rank(gpu_ctx, oracle):
+    import torch
+    from stark_mlwe_amd import dist as sd
+    leaves = oracle.synth_column(5, 1, 0, 4096)
+    prov = sd.HipProvider(gpu_ctx)
+    root = sd.merkle_sharded_root(prov, gpu_ctx.poseidon_params_for_width(17), 16, 9, torch.from_numpy(leaves.view(np.int64).copy()).cuda(), 4096)
+    assert (root.cpu().numpy().view(np.uint64) == oracle.merkle_build(16, 9, leaves).root()).all()
+    # a shard of a larger tree: levels built from leaves [2048, 4096) with global positions equal the right half of the full tree
+    h = prov.merkle_build(gpu_ctx.poseidon_params_for_width(17), 16, 9, torch.from_numpy(leaves[2048:].view(np.int64).copy()).cuda(), 2048, 2048, 0, 8)
+    top, nlev = prov.merkle_last_level(h)
+    full = oracle.merkle_build(16, 9, leaves)
+    assert nlev == 3 and (top.cpu().numpy().view(np.uint64) == full.level(2)[8:]).all()
+    prov.merkle_free(h)
