@@ -111,8 +111,19 @@ static int32_t ctx_leaf_init(stark_ctx* ctx, fr_t** out) {
         fr_t init[17]; for (auto& x : init) x = host::h_zero();
         init[0] = AB; init[1] = host::h_words("FRI/leaf/poseidon")[0]; init[2] = AB; init[3] = host::h_words("FRI/leaf")[0];
         /* lanes 4,5 = (f, s) */ init[6] = CH; init[7] = AB; init[8] = host::h_words("leaf")[0]; init[16] = host::h_tag("FSv1-TRANSCRIPT-INIT");
-        STARK_HIP(ctx, hipMalloc((void**)&ctx->leaf_init, sizeof(init)));
-        STARK_HIP(ctx, hipMemcpyAsync(ctx->leaf_init, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        // closed form of round 0 for the wave-pair kernel: K_i = sum_{j != 4,5} M[i][j] * (init_j + rc0_j)^5, then columns 4 and 5 of M
+        stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
+        const host::PoseidonConsts& c = tp->ref;
+        fr_t blob[17 + 51];
+        for (int j = 0; j < 17; ++j) blob[j] = init[j];
+        fr_t x[17]; for (int j = 0; j < 17; ++j) x[j] = fr_pow5<PallasFr>(host::h_add(init[j], c.rc_full[j]));
+        for (int i = 0; i < 17; ++i) {
+            fr_t k = host::h_zero();
+            for (int j = 0; j < 17; ++j) if (j != 4 && j != 5) k = host::h_add(k, host::h_mul(c.mds[(size_t)i * 17 + j], x[j]));
+            blob[17 + i] = k; blob[34 + i] = c.mds[(size_t)i * 17 + 4]; blob[51 + i] = c.mds[(size_t)i * 17 + 5];
+        }
+        STARK_HIP(ctx, hipMalloc((void**)&ctx->leaf_init, sizeof(blob)));
+        STARK_HIP(ctx, hipMemcpyAsync(ctx->leaf_init, blob, sizeof(blob), hipMemcpyHostToDevice, ctx->stream));
         STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     *out = ctx->leaf_init; return STARK_OK;
@@ -266,7 +277,7 @@ int32_t stark_leaf_pair_hash_dev(stark_ctx_t* ctx, stark_params_t* tp, const uin
     if (!n) return STARK_OK;
     fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
     if (use_pair(17)) {
-        hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), ctx->stream, tp->dev, init, as_fr(f), as_fr(f_next), n, m, as_fr(h));
+        hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), ctx->stream, tp->dev, init + 17, as_fr(f), as_fr(f_next), n, m, as_fr(h));
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     const int block = 64;

@@ -137,17 +137,20 @@ template <class F> FR_HD fr_t fr_mul_portable(const fr_t& a, const fr_t& b) {
 // ---- sums of products with ONE Montgomery reduction ("wide" accumulator) ----------------------------------
 // 15 independent 96-bit column accumulators {hi : ml}; W += a*b adds the 64 partial products of one
 // term, fr_wide_reduce folds in the Montgomery quotient terms and returns the fully reduced element.
-// Inputs must be reduced (< r); at most 32 terms per accumulator.  Used for the MDS / sparse-matrix
+// Inputs must be reduced (< r); at most 27 terms per accumulator (fr_reduce_wide_tail).  Used for the MDS / sparse-matrix
 // dot products of the Poseidon rounds: per extra term only the 64 MACs are paid, not the reduction.
 struct fr_wide { uint64_t ml[15]; uint32_t hi[15]; };
 FR_HD void fr_wide_zero(fr_wide& w) {
 #pragma unroll
     for (int c = 0; c < 15; ++c) { w.ml[c] = 0; w.hi[c] = 0; }
 }
-// t[0..8] < 16 r  ->  t[0..7] in [0, r): conditional subtraction of 8r, 4r, 2r, r.
+// t[0..8] < 2^(TAIL) r  ->  t[0..7] in [0, r): conditional subtraction of 2^(TAIL-1) r, ..., 2r, r.
+// A sum of L products of reduced operands leaves the Montgomery step below r (L r/2^256 + 1):
+// Pallas (r/2^256 ~ 1/4) stays under 8r up to L = 27, BLS12-381 (~0.45) under 16r up to L = 33.
 template <class F> FR_HD void fr_reduce_wide_tail(uint32_t* t) {
+    constexpr int TAIL = (F::P(7) >> 30) == 1 ? 3 : 4;
 #pragma unroll
-    for (int s = 3; s >= 0; --s) {
+    for (int s = TAIL - 1; s >= 0; --s) {
         uint32_t d[9]; uint64_t br = 0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {

@@ -76,9 +76,9 @@ __device__ __forceinline__ fr_t pair_dot_y(const PairState& s, const fr_t* sp, i
 }
 // One permutation by the wave pair.  Precondition: state consistent (a barrier since the last write).
 // Returns lane 0 of the result in BOTH waves; with only0 the rest of the state is dead afterwards.
-__device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonDev& P, bool only0) {
+__device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonDev& P, bool only0, int r_begin = 0) {
     const int t = P.t, half = P.rf / 2, w = 2 * t - 1;
-    for (int r = 0; r < half; ++r) {
+    for (int r = r_begin; r < half; ++r) {
         pair_sbox_full(s, P.rc_full + r * t, t);
         pair_apply_lu(s, (r == half - 1) ? P.lu_pre : P.lu, t);
     }
@@ -129,15 +129,24 @@ __device__ __forceinline__ PairState pair_setup(uint4* lds, int t) {
 }
 
 // K3 (pair form): h[i] = hash_leaf_pair(f[i], f_next[i/m] or 0).  Block = 128 threads = 64 states.
-__global__ void __launch_bounds__(128) k_leaf_pair2(PoseidonDev P, const fr_t* __restrict__ init, const fr_t* __restrict__ f,
+__global__ void __launch_bounds__(128) k_leaf_pair2(PoseidonDev P, const fr_t* __restrict__ leafc, const fr_t* __restrict__ f,
                                                     const fr_t* __restrict__ f_next, size_t n, size_t m, fr_t* __restrict__ h) {
     extern __shared__ uint4 lds[];
     PairState s = pair_setup(lds, 17);
     const size_t i = (size_t)blockIdx.x * 64 + s.lane; const bool live = i < n; const size_t ii = live ? i : n - 1;   // tail lanes recompute the last leaf
+    // Round 0 in closed form: 15 of the 17 lanes of the transcript template are constants, so after ARK and
+    // S-box the MDS output is  K_i + M[i][4]*x4 + M[i][5]*x5  with K precomputed on the host
+    // (leafc = [K(17) | M[:,4](17) | M[:,5](17)]).  Both waves compute x4, x5; each fills its own lanes.
+    const fr_t x4 = fr_pow5<PF>(fr_add<PF>(ldg(f + ii), P.rc_full[4]));
+    const fr_t x5 = fr_pow5<PF>(fr_add<PF>(f_next ? ldg(f_next + ii / m) : fr_zero<PF>(), P.rc_full[5]));
     const int j0 = s.isY ? s.nx : 0, j1 = s.isY ? 17 : s.nx;
-    for (int j = j0; j < j1; ++j) s.sto(j, j == 4 ? ldg(f + ii) : (j == 5 ? (f_next ? ldg(f_next + ii / m) : fr_zero<PF>()) : init[j]));
+    for (int j = j0; j < j1; ++j) {
+        fr_wide w; fr_wide_zero(w);
+        fr_wide_mac_f<PF>(w, leafc[17 + j], x4); fr_wide_mac_f<PF>(w, leafc[34 + j], x5);
+        s.sto(j, fr_add<PF>(leafc[j], fr_wide_reduce<PF>(w)));
+    }
     __syncthreads();
-    fr_t out = pair_permute(s, P, true);
+    fr_t out = pair_permute(s, P, true, 1);
     if (live && !s.isY) stg(h + i, out);
 }
 

@@ -78,7 +78,7 @@ def gen_wide(name, p):
     s += "    uint64_t ml = 0; uint32_t hi = 0, lo; uint32_t m0, m1, m2, m3, m4, m5, m6, m7; uint32_t t[9];\n"
     for c in range(15):
         s += f"    // column {c}: r += W[{c}]\n"
-        s += f"    {{ uint64_t x = ml + w.ml[{c}]; hi += w.hi[{c}] + (x < ml ? 1u : 0u); ml = x; }}\n"
+        s += f"    {{ unsigned long long x; const bool cy = __builtin_uaddll_overflow(ml, w.ml[{c}], &x); hi += w.hi[{c}] + (cy ? 1u : 0u); ml = x; }}\n"
         macs = []
         for k in range(max(0, c - 7), min(c - 1, 7) + 1):
             j = c - k
