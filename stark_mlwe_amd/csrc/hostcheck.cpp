@@ -39,6 +39,12 @@ int hc_fr_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* 
     }
     st4(out, z); return 0;
 }
+// sum_i a_i*b_i through the product's wide accumulator (DotAcc: one reduction per <= 24 terms)
+int hc_wide_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    DotAcc d; d.init();
+    for (size_t i = 0; i < n; ++i) d.mac(ld4(a + 4 * i), ld4(b + 4 * i));
+    st4(out, d.finish()); return 0;
+}
 int hc_blake3(const uint8_t* p, size_t n, uint8_t* out32) { host::Blake3::hash(p, n, out32); return 0; }
 int hc_chacha12_u64s(const uint8_t* seed32, size_t n, uint64_t* out) { host::ChaCha12Rng r(seed32); for (size_t i = 0; i < n; ++i) out[i] = r.next_u64(); return 0; }
 int hc_from_le_bytes_mod_order(const uint8_t* b, size_t n, uint64_t* out) { st4(out, host::h_from_le_bytes_mod_order(b, n)); return 0; }

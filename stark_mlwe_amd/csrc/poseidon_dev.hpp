@@ -33,19 +33,34 @@ struct ArrayState {
     FR_HD void st(int j, const fr_t& x) const { a[j] = x; }
 };
 
+// Dot product with one Montgomery reduction per <= 24 terms (fr_reduce_wide_tail covers sums of up to
+// 27 products; wide states, t = 33..129, have longer rows and are reduced in chunks).
+struct DotAcc {
+    fr_wide w; fr_t sum; int cnt; bool have_sum;
+    FR_HD void init() { fr_wide_zero(w); cnt = 0; have_sum = false; }
+    FR_HD void mac(const fr_t& a, const fr_t& b) {
+        fr_wide_mac_f<PF>(w, a, b);
+        if (++cnt == 24) { fr_t r = fr_wide_reduce<PF>(w); sum = have_sum ? fr_add<PF>(sum, r) : r; have_sum = true; fr_wide_zero(w); cnt = 0; }
+    }
+    FR_HD fr_t finish() {
+        if (!have_sum) return fr_wide_reduce<PF>(w);
+        return cnt ? fr_add<PF>(sum, fr_wide_reduce<PF>(w)) : sum;
+    }
+};
+
 // y = L*(U*x) in place.  U: row i needs x[j>=i] (top-down); unit-lower L: row i needs y[j<i] (bottom-up).
 // Every row is a dot product with wave-uniform constants: the 64-MAC partial products of all its terms
 // are summed in one wide accumulator and reduced once (fr.hpp "wide").
 template <class S> FR_HD void apply_lu(const S& s, const fr_t* lu, int t) {
     for (int i = 0; i < t; ++i) {
-        fr_wide w; fr_wide_zero(w);
-        for (int j = i; j < t; ++j) fr_wide_mac_f<PF>(w, lu[i * t + j], s.ld(j));
-        s.st(i, fr_wide_reduce<PF>(w));
+        DotAcc d; d.init();
+        for (int j = i; j < t; ++j) d.mac(lu[i * t + j], s.ld(j));
+        s.st(i, d.finish());
     }
     for (int i = t - 1; i >= 1; --i) {
-        fr_wide w; fr_wide_zero(w);
-        for (int j = 0; j < i; ++j) fr_wide_mac_f<PF>(w, lu[i * t + j], s.ld(j));
-        s.st(i, fr_add<PF>(s.ld(i), fr_wide_reduce<PF>(w)));
+        DotAcc d; d.init();
+        for (int j = 0; j < i; ++j) d.mac(lu[i * t + j], s.ld(j));
+        s.st(i, fr_add<PF>(s.ld(i), d.finish()));
     }
 }
 // One Poseidon permutation of the state behind `s`.  Returns lane 0 of the result.  With `only0`
@@ -61,22 +76,22 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
     for (int r = 0; r < P.rp; ++r) {
         const fr_t* sp = P.sparse + (size_t)r * w;
         s0 = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[r]));
-        fr_wide acc; fr_wide_zero(acc);
-        fr_wide_mac_f<PF>(acc, sp[0], s0);                         // s0' = a*s0 + sum_j u_j*s_j   (one reduction)
+        DotAcc acc; acc.init();
+        acc.mac(sp[0], s0);                                         // s0' = a*s0 + sum_j u_j*s_j
         for (int j = 1; j < t; ++j) {
             fr_t sj = s.ld(j);
-            fr_wide_mac_f<PF>(acc, sp[j], sj);
+            acc.mac(sp[j], sj);
             s.st(j, fr_add<PF>(sj, fr_mul<PF>(sp[t - 1 + j], s0)));  // s_j' = s_j + w_j*s0 (old s0)
         }
-        s0 = fr_wide_reduce<PF>(acc);
+        s0 = acc.finish();
     }
     s.st(0, s0);
     for (int r = half; r < P.rf; ++r) {
         for (int j = 0; j < t; ++j) s.st(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));
         if (only0 && r == P.rf - 1) {
-            fr_wide acc; fr_wide_zero(acc);
-            for (int j = 0; j < t; ++j) fr_wide_mac_f<PF>(acc, P.row0[j], s.ld(j));
-            return fr_wide_reduce<PF>(acc);
+            DotAcc acc; acc.init();
+            for (int j = 0; j < t; ++j) acc.mac(P.row0[j], s.ld(j));
+            return acc.finish();
         }
         apply_lu(s, P.lu, t);
     }

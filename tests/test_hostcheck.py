@@ -112,3 +112,15 @@ def test_hash_stream_body(oracle, hostcheck):
         ch = oracle.synth_column(2, 1, 0, cnt) if cnt else np.zeros((0, 4), np.uint64)
         assert (hostcheck.hash_stream(hseed, 1, None, 0, ch, cnt, tag) == oracle.hash_with_ds(2, ch, tag)).all(), cnt
     hostcheck.params_free(h17); hostcheck.params_free(hseed)
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 24, 25, 27, 48, 129])
+def test_wide_dot_worst_case_and_random(oracle, hostcheck, n):
+    """Sums of products with ONE Montgomery reduction per chunk: worst case (all operands r-1) and random."""
+    p = pyref.P_PALLAS
+    top = oracle.from_int(p - 1)
+    a = np.tile(top, (n, 1)); b = np.tile(top, (n, 1))
+    assert oracle.to_int(hostcheck.wide_dot(a, b)) == (n * (p - 1) * (p - 1)) % p
+    a = oracle.synth_column(17, 0, 0, n); b = oracle.synth_column(17, 1, 0, n)
+    want = sum(oracle.to_int(a[i]) * oracle.to_int(b[i]) for i in range(n)) % p
+    assert oracle.to_int(hostcheck.wide_dot(a, b)) == want
