@@ -8,6 +8,7 @@
 #include "ctx.hpp"
 #include "poseidon_dev.hpp"
 #include "poseidon_pair.hpp"
+#include "poseidon_coop.hpp"
 #include "fri_dev.hpp"
 
 using namespace stark;
@@ -34,13 +35,13 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     if (!P->kc.ok) return ctx->fail(STARK_ERR_UNSUPPORTED, "MDS matrix has a singular leading minor: LU/sparse kernel form unavailable");
     const host::KernelConsts& k = P->kc;
     std::vector<fr_t> blob; auto put = [&](const std::vector<fr_t>& v) { size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
-    size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds);
+    size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds), o_mpre = put(k.mds_pre);
     STARK_HIP(ctx, hipMalloc((void**)&P->blob, blob.size() * sizeof(fr_t)));
     STARK_HIP(ctx, hipMemcpyAsync(P->blob, blob.data(), blob.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     P->dev.t = k.t; P->dev.rf = k.rf; P->dev.rp = k.rp;
     P->dev.rc_full = P->blob + o_rcf; P->dev.rc_partial = P->blob + o_rcp; P->dev.lu = P->blob + o_lu; P->dev.lu_pre = P->blob + o_pre;
-    P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds;
+    P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds; P->dev.mds_pre = P->blob + o_mpre;
     return STARK_OK;
 }
 static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c, stark_params** out) {
@@ -88,6 +89,13 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tag, "out", &frame, &np, &ns));
     if (n == 0) return STARK_OK;
     TrJob J; J.prefix = frame; J.np = np; J.suffix = frame + np; J.ns = ns; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.k = k; J.n = n;
+    static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }();
+    if (!lane_only && n <= 4096) {
+        // few (or one, possibly very long) sponges: one wave per sponge, latency-oriented (poseidon_coop.hpp)
+        hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(), ctx->stream, tp->dev, J, fields_dev, out_dev);
+        STARK_HIP(ctx, hipGetLastError());
+        return STARK_OK;
+    }
     const int block = 64; const size_t lds = poseidon_lds(17, block);
     hipLaunchKernelGGL(k_tr_hash, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, ctx->stream, tp->dev, J, fields_dev, out_dev);
     STARK_HIP(ctx, hipGetLastError());

@@ -195,7 +195,8 @@ struct KernelConsts {
     std::vector<fr_t> lu, lu_pre;       // t*t each: U on/above the diagonal, strict lower = L (unit diagonal implied)
     std::vector<fr_t> row0;             // t: mds[0][*] (final round when only lane 0 is squeezed)
     std::vector<fr_t> sparse;           // rp*(2t-1): [a, u_1..u_{t-1}, w_1..w_{t-1}] in application order
-    std::vector<fr_t> mds;              // t*t reference form (kept for the cooperative kernels)
+    std::vector<fr_t> mds;              // t*t reference form (cooperative kernel: full rounds)
+    std::vector<fr_t> mds_pre;          // t*t dense B_1*M (cooperative kernel: last first-half full round)
     bool ok = false;
 };
 // Gauss-Jordan inverse of an n x n matrix (row-major); returns false when singular.
@@ -250,6 +251,7 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     // cur == B_1 * M == mds_pre
     if (!lu_pack(c.mds, t, k.lu)) return k;
     if (!lu_pack(cur, t, k.lu_pre)) return k;
+    k.mds_pre = cur;
     k.ok = true;
     return k;
 }

@@ -57,9 +57,9 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits =
 
 // All log_b DIF stages over the tile in LDS; slot(p, c) = p*C + c.  Output X[bitrev(p)] lands at p.
 template <class F>
-__device__ __forceinline__ void lds_dif(uint4* dlo, uint4* dhi, const uint4* tlo, const uint4* thi, int log_b, int log_c) {
+__device__ __forceinline__ void lds_dif(uint4* dlo, uint4* dhi, const uint4* tlo, const uint4* thi, int log_b, int log_c, int nstages) {
     const int B = 1 << log_b, C = 1 << log_c, nbf = (B >> 1) << log_c;
-    for (int s = 0; s < log_b; ++s) {
+    for (int s = 0; s < nstages; ++s) {
         const int log_half = log_b - 1 - s, half = 1 << log_half;
         for (int q = threadIdx.x; q < nbf; q += blockDim.x) {
             const int c = q & (C - 1), bq = q >> log_c;
@@ -73,10 +73,72 @@ __device__ __forceinline__ void lds_dif(uint4* dlo, uint4* dhi, const uint4* tlo
         __syncthreads();
     }
 }
+// The last TAIL (<= 3) DIF stages of one column block, in registers: x[0..2^TAIL) are consecutive points of
+// the block.  Their twiddles w_(2h)^pos have compile-time positions, so the trivial ones (pos == 0: all of
+// the last stage, half of the one before, ...) cost nothing: 5 products per 8 points instead of 12.
+template <class F, int TAIL>
+__device__ __forceinline__ void dif_tail(fr_t* x, const fr_t& w1, const fr_t& w2, const fr_t& w3) {   // w_k = w_8^k (TAIL == 3); w2 = w_4 (TAIL == 2)
+    if (TAIL == 3) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            fr_t a = x[p], b = x[p + 4]; x[p] = fr_add<F>(a, b); fr_t d = fr_sub<F>(a, b);
+            x[p + 4] = p == 0 ? d : fr_mul<F>(d, p == 1 ? w1 : (p == 2 ? w2 : w3));
+        }
+    }
+    if (TAIL >= 2) {
+#pragma unroll
+        for (int g = 0; g < (TAIL >= 2 ? (1 << (TAIL - 2)) : 0); ++g)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fr_t a = x[4 * g + p], b = x[4 * g + p + 2]; x[4 * g + p] = fr_add<F>(a, b); fr_t d = fr_sub<F>(a, b);
+                x[4 * g + p + 2] = p == 0 ? d : fr_mul<F>(d, w2);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < (1 << (TAIL - 1)); ++g) { fr_t a = x[2 * g], b = x[2 * g + 1]; x[2 * g] = fr_add<F>(a, b); x[2 * g + 1] = fr_sub<F>(a, b); }
+}
+
 template <class F>
 __device__ __forceinline__ void load_stage_tw(uint4* tlo, uint4* thi, const fr_t* tw, int log_b) {
     const int nt = (1 << log_b) >> 1;
     for (int i = threadIdx.x; i < nt; i += blockDim.x) lds_st(tlo, thi, i, ldg(tw + i));
+}
+
+// Last TAIL stages of every (column, block) of the tile in registers, then the pass epilogue straight from
+// the registers: STRIDED: inter-pass twiddle w_m^(rest*k) and in-place store; else the digit-reversing
+// store of the last pass (optional post-scale).
+template <class F, int TAIL, bool STRIDED>
+__device__ __forceinline__ void tail_store(const NttPassArgs& A, const uint4* dlo, const uint4* dhi, const uint4* tlo, const uint4* thi,
+                                           fr_t* dst, uint64_t tile, uint64_t k1_0, uint64_t k2) {
+    constexpr int NP = 1 << TAIL;
+    const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c, nblk = E >> TAIL;
+    fr_t w1 = fr_zero<F>(), w2 = fr_zero<F>(), w3 = fr_zero<F>();
+    if (TAIL == 3) { w1 = lds_ld(tlo, thi, B >> 3); w2 = lds_ld(tlo, thi, B >> 2); w3 = lds_ld(tlo, thi, 3 * (B >> 3)); }
+    else if (TAIL == 2) w2 = lds_ld(tlo, thi, B >> 2);
+    const int sh = A.log_n - A.log_m;                  // w_m = w_N^(2^sh)
+    for (int idx = threadIdx.x; idx < nblk; idx += blockDim.x) {
+        const int c = idx & (C - 1), blk = idx >> A.log_c;
+        fr_t x[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) x[p] = lds_ld(dlo, dhi, (((blk << TAIL) + p) << A.log_c) + c);
+        if (TAIL > 0) dif_tail<F, (TAIL > 0 ? TAIL : 1)>(x, w1, w2, w3);
+        const uint64_t rest = A.rest0 + (tile << A.log_c) + c;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint32_t k = bitrev((uint32_t)((blk << TAIL) + p), A.log_b);
+            fr_t y = x[p];
+            if (STRIDED) {
+                const uint64_t e = (rest * k) << sh;
+                if (e) y = fr_mul<F>(y, pow_lookup<F>(A.root, e));
+                stg(dst + (uint64_t)k * A.stride + c, y);
+            } else {
+                const uint64_t out = ((uint64_t)k << (A.log_b1 + A.log_b2)) + (k2 << A.log_b1) + k1_0 + c;
+                if (A.post.lo) y = fr_mul<F>(y, pow_lookup<F>(A.post, out));
+                else if (A.scale) y = fr_mul<F>(y, *A.scale);
+                stg(dst + out, y);
+            }
+        }
+    }
 }
 
 // Strided pass.  grid.x = (n / (B*S)) * (S / C) tiles.
@@ -97,16 +159,12 @@ __global__ void __launch_bounds__(256) k_ntt_strided(NttPassArgs A, const fr_t* 
         lds_st(dlo, dhi, idx, x);
     }
     __syncthreads();
-    lds_dif<F>(dlo, dhi, tlo, thi, A.log_b, A.log_c);
-    const int sh = A.log_n - A.log_m;                  // w_m = w_N^(2^sh)
-    for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
-        const int c = idx & (C - 1); const uint32_t k = idx >> A.log_c;
-        fr_t x = lds_ld(dlo, dhi, (int)(bitrev(k, A.log_b) << A.log_c) + c);
-        const uint64_t rest = A.rest0 + (tile << A.log_c) + c;
-        const uint64_t e = (rest * k) << sh;
-        if (e) x = fr_mul<F>(x, pow_lookup<F>(A.root, e));
-        stg(dst + base + (uint64_t)k * A.stride + c, x);
-    }
+    const int tail = A.log_b >= 3 ? 3 : A.log_b;
+    lds_dif<F>(dlo, dhi, tlo, thi, A.log_b, A.log_c, A.log_b - tail);
+    if (tail == 3) tail_store<F, 3, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
+    else if (tail == 2) tail_store<F, 2, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
+    else if (tail == 1) tail_store<F, 1, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
+    else tail_store<F, 0, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
 }
 
 // Last (contiguous) pass with the digit-reversing store.  grid.x = n / (B*C) tiles.
@@ -131,15 +189,12 @@ __global__ void __launch_bounds__(256) k_ntt_last(NttPassArgs A, const fr_t* src
         lds_st(dlo, dhi, (p << A.log_c) + c, x);
     }
     __syncthreads();
-    lds_dif<F>(dlo, dhi, tlo, thi, A.log_b, A.log_c);
-    for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
-        const int c = idx & (C - 1); const uint32_t k = idx >> A.log_c;
-        fr_t x = lds_ld(dlo, dhi, (int)(bitrev(k, A.log_b) << A.log_c) + c);
-        const uint64_t out = ((uint64_t)k << (A.log_b1 + A.log_b2)) + (k2 << A.log_b1) + k1_0 + c;
-        if (A.post.lo) x = fr_mul<F>(x, pow_lookup<F>(A.post, out));
-        else if (A.scale) x = fr_mul<F>(x, *A.scale);
-        stg(dst + out, x);
-    }
+    const int tail = A.log_b >= 3 ? 3 : A.log_b;
+    lds_dif<F>(dlo, dhi, tlo, thi, A.log_b, A.log_c, A.log_b - tail);
+    if (tail == 3) tail_store<F, 3, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
+    else if (tail == 2) tail_store<F, 2, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
+    else if (tail == 1) tail_store<F, 1, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
+    else tail_store<F, 0, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
 }
 
 // Fill a PowTable: lo[i] = c0 * g^i (i < 2^lo_bits), hi[i] = g^(i << lo_bits) (i < 2^hi_bits).

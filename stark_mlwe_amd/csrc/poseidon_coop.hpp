@@ -1,0 +1,112 @@
+// stark_mlwe_amd/csrc/poseidon_coop.hpp — ONE wave per sponge: the latency-oriented form (gfx950).
+//
+// For chains that cannot be batched: the four serial column sponges of DeepAliRealBuilder::build_f0
+// (crates/deep_ali/src/fri.rs:548-557 via tr_hash_fields_tagged, fri.rs:28-35 — n0/16 DEPENDENT t=17
+// permutations per column) and the single Fiat-Shamir hashes (fri_sample_z_ell, fs_seed_from_roots,
+// ali_sample_z_beta_fs).  A lane-per-sponge kernel would run such a chain on one lane (~1.4 ms per
+// permutation measured); here the 64 lanes of one wave share one permutation:
+//   * lane j < 17 holds state element j in registers;
+//   * full rounds: S-boxes in parallel (3 product latencies), then the dense MDS with the row split
+//     three ways over lanes (i, q), q = 0..2 (51 lanes): each sums ~6 terms of row i in a wide
+//     accumulator, the three partials are added across lanes; the MDS matrix sits in LDS;
+//   * partial rounds (sparse form): while lane 0 computes x^2 of the S-box the other lanes already form
+//     u_j*s_j; after the S-box one more parallel product gives a*s0 and w_j*s0, then a shuffle tree
+//     sums the 17 partial products: 4 product latencies + one reduction per round instead of 36 products.
+// Same field values as the reference's dense rounds (the kernel-form constants of host_util.hpp).
+#pragma once
+#include "fr.hpp"
+#include "dev_common.hpp"
+#include "poseidon_params.hpp"
+#include "poseidon_dev.hpp"   // TrJob
+
+#if defined(__HIPCC__)
+namespace stark {
+
+__device__ __forceinline__ fr_t shfl_fr(const fr_t& x, int src) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl((int)x.v[i], src, 64);
+    return r;
+}
+__device__ __forceinline__ fr_t shfl_down_fr(const fr_t& x, int d) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], d, 64);
+    return r;
+}
+struct CoopLds { uint4* mds; uint4* mpre; uint4* x; };   // [289][2], [289][2], [17][2]
+__device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
+    uint4 lo = base[2 * idx], hi = base[2 * idx + 1];
+    fr_t x; x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w; return x;
+}
+__device__ __forceinline__ void lds_put(uint4* base, int idx, const fr_t& x) {
+    base[2 * idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]); base[2 * idx + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+static inline size_t coop_lds_bytes() { return (size_t)(289 * 2 * 2 + 17 * 2) * 16; }
+
+// s: this lane's state element (lanes 0..16 meaningful).  Returns the permuted element.
+__device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const CoopLds& L, int lane) {
+    const int t = 17, half = P.rf / 2, w = 2 * t - 1;
+    const int row = lane % 17, q = lane / 17;                  // (i, q) split of the dense rows; q == 3 lanes idle
+    const int j0 = q * 6, j1 = q == 2 ? 17 : j0 + 6;
+    const bool elem = lane < 17;
+    auto full_round = [&](int r, const uint4* M) {
+        if (elem) { s = fr_pow5<PF>(fr_add<PF>(s, ldg(P.rc_full + r * t + lane))); lds_put(L.x, lane, s); }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): one wave, LDS is in order — make the writes land before the reads
+        __builtin_amdgcn_wave_barrier();
+        fr_t part = fr_zero<PF>();
+        if (q < 3) {
+            fr_wide acc; fr_wide_zero(acc);
+            for (int j = j0; j < j1; ++j) fr_wide_mac_f<PF>(acc, lds_get(M, row * 17 + j), lds_get(L.x, j));
+            part = fr_wide_reduce<PF>(acc);
+        }
+        fr_t p1 = shfl_fr(part, (lane + 17) & 63), p2 = shfl_fr(part, (lane + 34) & 63);
+        if (elem) s = fr_add<PF>(fr_add<PF>(part, p1), p2);
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int r = 0; r < half; ++r) full_round(r, r == half - 1 ? L.mpre : L.mds);
+    // partial rounds: constants of round r for this lane: lane 0 -> (a, rc_partial), lane j -> (u_j, w_j)
+    for (int r = 0; r < P.rp; ++r) {
+        const fr_t* sp = P.sparse + (size_t)r * w;
+        const fr_t cu = elem ? ldg(sp + lane) : fr_zero<PF>();                       // a (lane 0) / u_j
+        const fr_t cw = (elem && lane > 0) ? ldg(sp + t - 1 + lane) : fr_zero<PF>();  // w_j
+        // slot 1: lane 0: x^2 with x = s0 + rc ; lanes j: u_j * s_j
+        fr_t x = fr_add<PF>(s, ldg(P.rc_partial + r));
+        fr_t m1 = fr_mul<PF>(lane == 0 ? x : cu, lane == 0 ? x : s);
+        // slots 2,3 (lane 0 only; the other lanes run along masked): x^4, x^5
+        fr_t x4 = fr_mul<PF>(m1, m1);
+        fr_t x5 = fr_mul<PF>(x, x4);
+        const fr_t s0n = shfl_fr(x5, 0);                                             // s0 after the S-box, to every lane
+        // slot 4: lane 0: a*s0 ; lanes j: w_j*s0
+        fr_t m4 = fr_mul<PF>(lane == 0 ? cu : cw, s0n);
+        fr_t term = lane == 0 ? m4 : (elem ? m1 : fr_zero<PF>());                    // summands of s0' = a*s0 + sum u_j s_j
+        for (int d = 16; d >= 1; d >>= 1) { fr_t o = shfl_down_fr(term, d); if (lane + d < 32) term = fr_add<PF>(term, o); }
+        if (lane == 0) s = term; else if (elem) s = fr_add<PF>(s, m4);
+    }
+    for (int r = half; r < P.rf; ++r) full_round(r, L.mds);
+    return s;
+}
+
+// tr_hash_fields_tagged over the stream prefix || fields_i || suffix, one 64-lane block per hash i.
+__global__ void __launch_bounds__(64) k_tr_hash_coop(PoseidonDev P, TrJob J, const fr_t* __restrict__ fields, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    CoopLds L{lds, lds + 289 * 2, lds + 289 * 4};
+    const int lane = threadIdx.x; const size_t i = blockIdx.x;
+    for (int k = lane; k < 289; k += 64) { lds_put(L.mds, k, ldg(P.mds + k)); lds_put(L.mpre, k, ldg(P.mds_pre + k)); }
+    __syncthreads();
+    fr_t s = lane == 16 ? J.cap : fr_zero<PF>();
+    const size_t total = (size_t)J.np + J.k + (size_t)J.ns;
+    for (size_t base = 0; base < total; base += 16) {                                // one rate-16 block per iteration
+        if (base) s = coop_permute(s, P, L, lane);                                   // lazy permute: only before absorbing more
+        const size_t e = base + lane;
+        if (lane < 16 && e < total) {
+            fr_t x = e < (size_t)J.np ? ldg(J.prefix + e) : (e < (size_t)J.np + J.k ? ldg(fields + i * J.k + (e - J.np)) : ldg(J.suffix + (e - J.np - J.k)));
+            s = fr_add<PF>(s, x);
+        }
+    }
+    s = coop_permute(s, P, L, lane);
+    if (lane == 0) stg(out + i, s);
+}
+
+}  // namespace stark
+#endif

@@ -11,6 +11,7 @@ struct PoseidonDev {           // device pointers to kernel-form constants (see 
     const fr_t* row0;          // t    M[0][*]
     const fr_t* sparse;        // rp*(2t-1)
     const fr_t* mds;           // t*t  reference form
+    const fr_t* mds_pre;       // t*t  dense B_1*M
 };
 
 }  // namespace stark
