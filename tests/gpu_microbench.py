@@ -38,6 +38,12 @@ def main():
         ms = timed(lambda: ctx._chk(lib.stark_fri_fold_dev(ctx.h, C.c_void_p(f.data_ptr()), n, _ptr(z), 16, C.c_void_p(out.data_ptr()))))
         print(json.dumps({"kernel": "fri_fold_m16", "log_n": lg, "ms": ms, "GBps": 32.0 * n * (1 + 1 / 16) / ms / 1e6}), flush=True)
         del f, fn, h, out
+    # serial column sponge (tr_hash_fields_tagged over one column): latency per dependent permutation
+    for lg in (12, 16):
+        n = 1 << lg; f, o = dbuf(n), dbuf(1)
+        ctx._chk(lib.stark_synth_column_dev(ctx.h, 1, 0, 0, n, C.c_void_p(f.data_ptr())))
+        ms = timed(lambda: ctx._chk(lib.stark_tr_hash_fields_tagged_dev(ctx.h, None, b"ALI/A", C.c_void_p(f.data_ptr()), n, 1, C.c_void_p(o.data_ptr()))), reps=1)
+        print(json.dumps({"kernel": "column_sponge", "log_n": lg, "ms": ms, "us_per_permutation": ms * 1e3 / (n / 16)}), flush=True)
     ctx.close()
 
 

@@ -317,3 +317,46 @@ def test_sharded_merkle_single_rank(gpu_ctx, oracle):
     full = oracle.merkle_build(16, 9, leaves)
     assert nlev == 3 and (top.cpu().numpy().view(np.uint64) == full.level(2)[8:]).all()
     prov.merkle_free(h)
+
+
+# ---- BASELINE sizes: the oracle where it finishes in seconds, size-independent properties beyond ---------------
+def test_leaf_hash_2pow20_sampled_against_oracle(gpu_ctx, oracle):
+    """2^20 leaves through the wave-pair kernel; 2048 positions (incl. both ends) checked against the oracle."""
+    n, m = 1 << 20, 16
+    f, fn = oracle.synth_column(20, 0, 0, n), oracle.synth_column(20, 1, 0, n // m)
+    h = gpu_ctx.leaf_pair_hash(f, fn, m)
+    rng = np.random.default_rng(7)
+    idx = np.unique(np.concatenate([[0, 1, 63, 64, n - 65, n - 64, n - 1], rng.integers(0, n, 2048)]))
+    want = oracle.leaf_pair_hash(f[idx], fn[idx // m], 1)
+    assert (h[idx] == want).all()
+
+
+def test_merkle_2pow18_root_against_oracle(gpu_ctx, oracle):
+    leaves = oracle.synth_column(21, 3, 0, 1 << 18)
+    t = gpu_ctx.merkle_new(leaves, gpu_ctx.merkle_cfg(16, 5))
+    o = oracle.merkle_build(16, 5, leaves)
+    assert t.num_levels == 6 and (t.root() == o.root()).all()
+    assert (t.level(2) == o.level(2)).all()
+    t.free(); o.free()
+
+
+def test_fold_and_ntt_properties_at_full_size(gpu_ctx, oracle):
+    """n = 2^22: fold is linear in f; NTT round trip and Parseval-free checks (delta, constant) on the device."""
+    n = 1 << 22
+    f, g = oracle.synth_column(22, 0, 0, n), oracle.synth_column(22, 1, 0, n)
+    z = oracle.fri_sample_z_ell(0xDEEFBAAD, 0, n)
+    ff, fg = gpu_ctx.fri_fold_layer(f, z, 16), gpu_ctx.fri_fold_layer(g, z, 16)
+    import ctypes as C
+    # (f + g) computed limb-wise by the oracle on a sample is enough: fold(f+g)[b] == fold(f)[b] + fold(g)[b]
+    bs = [0, 1, 12345, (n // 16) - 1]
+    for b in bs:
+        seg = np.array([oracle.add(f[16 * b + t], g[16 * b + t]) for t in range(16)])
+        assert (oracle.fri_fold_layer(seg, z, 16)[0] == oracle.add(ff[b], fg[b])).all()
+        assert (oracle.fri_fold_layer(f[16 * b:16 * b + 16], z, 16)[0] == ff[b]).all()
+    y = gpu_ctx.fft(f, field=PALLAS_FR)
+    assert (gpu_ctx.ifft(y, field=PALLAS_FR) == f).all()
+    s = oracle.from_u64(0)
+    # DC term = sum of inputs (checked on a strided subsample via linearity: NTT of a constant vector is n*c at 0)
+    c = np.tile(oracle.from_u64(3), (n, 1))
+    yc = gpu_ctx.fft(c, field=PALLAS_FR)
+    assert (yc[0] == oracle.from_u64(3 * n)).all() and not yc[1:].any()
