@@ -92,7 +92,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }();
     if (!lane_only && n <= 4096) {
         // few (or one, possibly very long) sponges: one wave per sponge, latency-oriented (poseidon_coop.hpp)
-        hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(), ctx->stream, tp->dev, J, fields_dev, out_dev);
+        hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, fields_dev, out_dev);
         STARK_HIP(ctx, hipGetLastError());
         return STARK_OK;
     }
@@ -258,6 +258,12 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, stark_params_t* p, int mode, siz
     DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
     J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
     if (!J.n_out) return STARK_OK;
+    if (use_pair(p->dev.t) && J.n_out <= 2048) {
+        // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
+        if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), ctx->stream, p->dev, J, in0, in1, out);
+        else hipLaunchKernelGGL(k_hash_ds_coop<9>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(9), ctx->stream, p->dev, J, in0, in1, out);
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
     if (use_pair(p->dev.t)) {
         hipLaunchKernelGGL(k_hash_ds2, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(p->dev.t), ctx->stream, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;

@@ -34,7 +34,7 @@ __device__ __forceinline__ fr_t shfl_down_fr(const fr_t& x, int d) {
     for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], d, 64);
     return r;
 }
-struct CoopLds { uint4* mds; uint4* mpre; uint4* x; };   // [289][2], [289][2], [17][2]
+struct CoopLds { uint4* mds; uint4* mpre; uint4* x; };   // [T*T][2], [T*T][2], [T][2]
 __device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
     uint4 lo = base[2 * idx], hi = base[2 * idx + 1];
     fr_t x; x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w; return x;
@@ -42,26 +42,37 @@ __device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
 __device__ __forceinline__ void lds_put(uint4* base, int idx, const fr_t& x) {
     base[2 * idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]); base[2 * idx + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
-static inline size_t coop_lds_bytes() { return (size_t)(289 * 2 * 2 + 17 * 2) * 16; }
+static inline size_t coop_lds_bytes(int t) { return (size_t)(t * t * 2 * 2 + t * 2) * 16; }
+template <int T> __device__ __forceinline__ CoopLds coop_setup(uint4* lds, const PoseidonDev& P) {
+    CoopLds L{lds, lds + T * T * 2, lds + T * T * 4};
+    for (int k = threadIdx.x; k < T * T; k += 64) { lds_put(L.mds, k, ldg(P.mds + k)); lds_put(L.mpre, k, ldg(P.mds_pre + k)); }
+    __syncthreads();
+    return L;
+}
 
-// s: this lane's state element (lanes 0..16 meaningful).  Returns the permuted element.
+// s: this lane's state element (lanes 0..T-1 meaningful).  Returns the permuted element.
+// T = 17: rows split 3 ways (51 lanes); T = 9: 7 ways (63 lanes).
+template <int T>
 __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const CoopLds& L, int lane) {
-    const int t = 17, half = P.rf / 2, w = 2 * t - 1;
-    const int row = lane % 17, q = lane / 17;                  // (i, q) split of the dense rows; q == 3 lanes idle
-    const int j0 = q * 6, j1 = q == 2 ? 17 : j0 + 6;
-    const bool elem = lane < 17;
+    constexpr int NS = 64 / T, PER = (T + NS - 1) / NS;
+    const int half = P.rf / 2, w = 2 * T - 1;
+    const int row = lane % T, q = lane / T;
+    const int j0 = q * PER, j1 = (j0 + PER < T) ? j0 + PER : T;
+    const bool elem = lane < T;
     auto full_round = [&](int r, const uint4* M) {
-        if (elem) { s = fr_pow5<PF>(fr_add<PF>(s, ldg(P.rc_full + r * t + lane))); lds_put(L.x, lane, s); }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): one wave, LDS is in order — make the writes land before the reads
+        if (elem) { s = fr_pow5<PF>(fr_add<PF>(s, ldg(P.rc_full + r * T + lane))); lds_put(L.x, lane, s); }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         fr_t part = fr_zero<PF>();
-        if (q < 3) {
+        if (q < NS && j0 < T) {
             fr_wide acc; fr_wide_zero(acc);
-            for (int j = j0; j < j1; ++j) fr_wide_mac_f<PF>(acc, lds_get(M, row * 17 + j), lds_get(L.x, j));
+            for (int j = j0; j < j1; ++j) fr_wide_mac_f<PF>(acc, lds_get(M, row * T + j), lds_get(L.x, j));
             part = fr_wide_reduce<PF>(acc);
         }
-        fr_t p1 = shfl_fr(part, (lane + 17) & 63), p2 = shfl_fr(part, (lane + 34) & 63);
-        if (elem) s = fr_add<PF>(fr_add<PF>(part, p1), p2);
+        fr_t tot = part;
+#pragma unroll
+        for (int k = 1; k < NS; ++k) { fr_t o = shfl_fr(part, (lane + k * T) & 63); tot = fr_add<PF>(tot, o); }
+        if (elem) s = tot;
         __builtin_amdgcn_wave_barrier();
     };
     for (int r = 0; r < half; ++r) full_round(r, r == half - 1 ? L.mpre : L.mds);
@@ -69,11 +80,11 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     for (int r = 0; r < P.rp; ++r) {
         const fr_t* sp = P.sparse + (size_t)r * w;
         const fr_t cu = elem ? ldg(sp + lane) : fr_zero<PF>();                       // a (lane 0) / u_j
-        const fr_t cw = (elem && lane > 0) ? ldg(sp + t - 1 + lane) : fr_zero<PF>();  // w_j
+        const fr_t cw = (elem && lane > 0) ? ldg(sp + T - 1 + lane) : fr_zero<PF>();  // w_j
         // slot 1: lane 0: x^2 with x = s0 + rc ; lanes j: u_j * s_j
         fr_t x = fr_add<PF>(s, ldg(P.rc_partial + r));
         fr_t m1 = fr_mul<PF>(lane == 0 ? x : cu, lane == 0 ? x : s);
-        // slots 2,3 (lane 0 only; the other lanes run along masked): x^4, x^5
+        // slots 2,3 (lane 0 only; the other lanes run along): x^4, x^5
         fr_t x4 = fr_mul<PF>(m1, m1);
         fr_t x5 = fr_mul<PF>(x, x4);
         const fr_t s0n = shfl_fr(x5, 0);                                             // s0 after the S-box, to every lane
@@ -90,22 +101,43 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
 // tr_hash_fields_tagged over the stream prefix || fields_i || suffix, one 64-lane block per hash i.
 __global__ void __launch_bounds__(64) k_tr_hash_coop(PoseidonDev P, TrJob J, const fr_t* __restrict__ fields, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
-    CoopLds L{lds, lds + 289 * 2, lds + 289 * 4};
+    CoopLds L = coop_setup<17>(lds, P);
     const int lane = threadIdx.x; const size_t i = blockIdx.x;
-    for (int k = lane; k < 289; k += 64) { lds_put(L.mds, k, ldg(P.mds + k)); lds_put(L.mpre, k, ldg(P.mds_pre + k)); }
-    __syncthreads();
     fr_t s = lane == 16 ? J.cap : fr_zero<PF>();
     const size_t total = (size_t)J.np + J.k + (size_t)J.ns;
     for (size_t base = 0; base < total; base += 16) {                                // one rate-16 block per iteration
-        if (base) s = coop_permute(s, P, L, lane);                                   // lazy permute: only before absorbing more
+        if (base) s = coop_permute<17>(s, P, L, lane);                               // lazy permute: only before absorbing more
         const size_t e = base + lane;
         if (lane < 16 && e < total) {
             fr_t x = e < (size_t)J.np ? ldg(J.prefix + e) : (e < (size_t)J.np + J.k ? ldg(fields + i * J.k + (e - J.np)) : ldg(J.suffix + (e - J.np - J.k)));
             s = fr_add<PF>(s, x);
         }
     }
-    s = coop_permute(s, P, L, lane);
+    s = coop_permute<17>(s, P, L, lane);
     if (lane == 0) stg(out + i, s);
+}
+
+// One Merkle node per wave (small levels: latency matters, not throughput).  Same job as k_hash_ds.
+template <int T>
+__global__ void __launch_bounds__(64) k_hash_ds_coop(PoseidonDev P, DsJob J, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    CoopLds L = coop_setup<T>(lds, P);
+    const int lane = threadIdx.x, rate = T - 1; const size_t k = blockIdx.x;
+    const size_t cnt = J.mode == 1 ? 2 : ((k + 1) * J.arity <= J.n_in ? J.arity : J.n_in - k * J.arity);
+    const size_t total = 4 + cnt + 1;                                                // ds || children || 1, zero padded
+    fr_t s = fr_zero<PF>();
+    for (size_t base = 0; base < total; base += rate) {                              // eager sponge: permute after every full (or final) block
+        const size_t q = base + lane;
+        if (lane < rate && q < total) {
+            fr_t x;
+            if (q == 0) x = J.arity_f; else if (q == 1) x = J.level_f; else if (q == 2) x = fr_from_u64<PF>(J.pos0 + k); else if (q == 3) x = J.label_f;
+            else if (q == total - 1) x = fr_one<PF>();
+            else { size_t c = q - 4; x = J.mode == 1 ? ldg((c == 0 ? in0 : in1) + k) : ldg(in0 + k * J.arity + c); }
+            s = fr_add<PF>(s, x);
+        }
+        s = coop_permute<T>(s, P, L, lane);
+    }
+    if (lane == 0) stg(out + k, s);
 }
 
 }  // namespace stark
