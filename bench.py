@@ -139,6 +139,25 @@ def main():
     leaf_ms = ms.value
     del scratch, h, fnext
 
+    # ---- the reference's own bench shape (deep_fri_prove, schedule [16,16,8], r = 32; end_to_end.rs:187-270) ----
+    def prove(log_k, given_f0):
+        nk = 1 << log_k
+        cs = [dbuf(nk) for _ in range(4)]
+        for c in range(4):
+            ctx._chk(lib.stark_synth_column_dev(ctx.h, 0x5EED0000 + log_k, c, 0, nk, C.c_void_p(cs[c].data_ptr())))
+        ph = C.c_void_p()
+        args = [C.c_void_p(x.data_ptr()) for x in cs]
+        t0 = time.perf_counter()
+        ctx._chk(lib.stark_deep_fri_prove_dev(ctx.h, *( [None] * 4 + [args[0]] if given_f0 else args + [None]), nk, _ptr(sched), L, 32, SEED_Z, C.byref(ph)))
+        wall = (time.perf_counter() - t0) * 1e3
+        res = {"log_n0": log_k, "r": 32, "wall_ms": wall, "proof_bytes": int(lib.stark_proof_len(ph)), "size_estimate": int(lib.stark_proof_size_estimate(ph)),
+               "build_f0_ms": lib.stark_proof_stage_ms(ph, 0), "fri_build_ms": lib.stark_proof_stage_ms(ph, 1), "queries_encode_ms": lib.stark_proof_stage_ms(ph, 2)}
+        lib.stark_proof_free(ph)
+        return res
+    prove(12, False)                                   # warm the constants / plans
+    prove_e2e = prove(16, False)                       # DeepAliRealBuilder incl. the four serial column sponges
+    prove_f0 = prove(20, True)                         # "prove given f0": everything after build_f0
+
     out = None
     if rank == 0:
         traffic = None
@@ -165,6 +184,8 @@ def main():
                          "frac": ntt_gbps / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes": ntt_bytes, "avg_ms": ntt_ms},
             "poseidon": {"kernel": "k_leaf_pair (t=17), 2^%d leaves" % (log_n + LOG_BLOWUP), "ms": leaf_ms, "leaves_per_s": N / (leaf_ms * 1e-3),
                          "reference_dense_fr_mults_per_s": FR_MULTS_T17 * N / (leaf_ms * 1e-3), "bound": "integer VALU (not HBM, not MFMA)"},
+            "prove_end_to_end": dict(prove_e2e, note="deep_fri_prove with DeepAliRealBuilder on a 2^16-row trace (device-resident columns); build_f0 is the serial column sponge (fri.rs:548-557)"),
+            "prove_given_f0": dict(prove_f0, note="deep_fri_prove stages after build_f0 on n0 = 2^20"),
             "roots": ["".join(f"{int(x):016x}" for x in r[::-1]) for r in roots],
         }
         if not args.no_cpu_baseline and world == 1:

@@ -52,7 +52,8 @@ static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c,
 }
 int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out) {
     if (!ctx->tparams) STARK_TRY(params_from_consts(ctx, host::consts_transcript(), &ctx->tparams));
-    *out = ctx->tparams; return STARK_OK;
+    if (out) *out = ctx->tparams;
+    return STARK_OK;
 }
 int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out) {
     auto it = ctx->merkle_params.find(t);
@@ -84,7 +85,8 @@ static int32_t tr_frame(stark_ctx* ctx, const char* label, const char* tag, cons
     }
     *dev = it->second; *np = ctx->tr_frame_dims[key].first; *ns = ctx->tr_frame_dims[key].second; return STARK_OK;
 }
-int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev) {
+int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev, hipStream_t on) {
+    hipStream_t st = on ? on : ctx->stream;
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
     fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tag, "out", &frame, &np, &ns));
     if (n == 0) return STARK_OK;
@@ -92,12 +94,12 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }();
     if (!lane_only && n <= 4096) {
         // few (or one, possibly very long) sponges: one wave per sponge, latency-oriented (poseidon_coop.hpp)
-        hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, fields_dev, out_dev);
+        hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(17), st, tp->dev, J, fields_dev, out_dev);
         STARK_HIP(ctx, hipGetLastError());
         return STARK_OK;
     }
     const int block = 64; const size_t lds = poseidon_lds(17, block);
-    hipLaunchKernelGGL(k_tr_hash, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, ctx->stream, tp->dev, J, fields_dev, out_dev);
+    hipLaunchKernelGGL(k_tr_hash, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, st, tp->dev, J, fields_dev, out_dev);
     STARK_HIP(ctx, hipGetLastError());
     return STARK_OK;
 }
@@ -170,6 +172,8 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (ctx->leaf_init) (void)hipFree(ctx->leaf_init);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0); if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto& s : ctx->side) if (s) (void)hipStreamDestroy(s);
+    for (auto& e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx; return STARK_OK;
 }
