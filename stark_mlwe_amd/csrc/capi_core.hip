@@ -85,8 +85,8 @@ static int32_t tr_frame(stark_ctx* ctx, const char* label, const char* tag, cons
     }
     *dev = it->second; *np = ctx->tr_frame_dims[key].first; *ns = ctx->tr_frame_dims[key].second; return STARK_OK;
 }
-int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev, hipStream_t on) {
-    hipStream_t st = on ? on : ctx->stream;
+int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev) {
+    hipStream_t st = ctx->stream;
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
     fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tag, "out", &frame, &np, &ns));
     if (n == 0) return STARK_OK;
@@ -100,6 +100,18 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     }
     const int block = 64; const size_t lds = poseidon_lds(17, block);
     hipLaunchKernelGGL(k_tr_hash, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, st, tp->dev, J, fields_dev, out_dev);
+    STARK_HIP(ctx, hipGetLastError());
+    return STARK_OK;
+}
+// The four column sponges of DeepAliRealBuilder::build_f0 (fri.rs:551-554) as one launch of four blocks.
+int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev) {
+    stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
+    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT");
+    for (int c = 0; c < 4; ++c) {
+        fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tags[c], "out", &frame, &np, &ns));
+        J.prefix[c] = frame; J.np[c] = np; J.suffix[c] = frame + np; J.ns[c] = ns; J.fields[c] = cols[c]; J.k[c] = n0;
+    }
+    hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(4), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out4_dev);
     STARK_HIP(ctx, hipGetLastError());
     return STARK_OK;
 }
@@ -172,8 +184,7 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (ctx->leaf_init) (void)hipFree(ctx->leaf_init);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0); if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    for (auto& s : ctx->side) if (s) (void)hipStreamDestroy(s);
-    for (auto& e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
+
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx; return STARK_OK;
 }

@@ -171,17 +171,7 @@ static int32_t build_f0_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, c
     // four serial column sponges (fri.rs:551-554): one lane per column, inherently sequential in n0
     DevBuf dig; STARK_HIP(ctx, dig.alloc(4 * sizeof(fr_t)));
     const fr_t* cols[4] = {a, s, e, t}; const char* tags[4] = {"ALI/A", "ALI/S", "ALI/E", "ALI/T"};
-    // the chains are independent of each other: column c runs on its own stream (fork after the inputs are ready, join before the digests are read)
-    for (int c = 0; c < 3; ++c) if (!ctx->side[c]) STARK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[c], hipStreamNonBlocking));
-    for (int c = 0; c < 4; ++c) if (!ctx->side_ev[c]) STARK_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[c], hipEventDisableTiming));
-    STARK_TRY(ctx_transcript_params(ctx, nullptr));                          // constants uploaded on the main stream before the fork
-    STARK_HIP(ctx, hipEventRecord(ctx->side_ev[3], ctx->stream));
-    for (int c = 0; c < 4; ++c) {
-        hipStream_t st = c < 3 ? ctx->side[c] : ctx->stream;
-        if (c < 3) STARK_HIP(ctx, hipStreamWaitEvent(st, ctx->side_ev[3], 0));
-        STARK_TRY(tr_hash_dev(ctx, tags[c], cols[c], n0, 1, dig.fr() + c, st));
-        if (c < 3) { STARK_HIP(ctx, hipEventRecord(ctx->side_ev[c], st)); STARK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[c], 0)); }
-    }
+    STARK_TRY(tr_hash_columns4_dev(ctx, tags, cols, n0, dig.fr()));           // the chains are independent: one launch, four concurrent blocks
     fr_t h[5]; STARK_HIP(ctx, hipMemcpyAsync(h, dig.p, 4 * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h[4] = host::h_u64(n0);
     fr_t seed_f; STARK_TRY(tr_hash_host1(ctx, "ALI/seed", std::vector<fr_t>(h, h + 5), &seed_f));

@@ -31,8 +31,6 @@ struct stark_ctx {
     bool own_stream = false;
     std::string err;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams: the four independent column sponges of build_f0 run concurrently
-    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // lazily created constants
     stark_params* tparams = nullptr;                 // transcript params (t=17, "POSEIDON-T17-X5-TRANSCRIPT")
     std::map<int, stark_params*> merkle_params;      // poseidon_params_for_width(t)
@@ -92,7 +90,8 @@ int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out);
 int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out);
 int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out);
 void ntt_plans_free(stark_ctx* ctx);
-int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev, hipStream_t on = nullptr);
+int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev);
+int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev);
 int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out);   // one hash, host in/out
 
 }  // namespace stark

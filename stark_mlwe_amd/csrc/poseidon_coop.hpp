@@ -117,6 +117,24 @@ __global__ void __launch_bounds__(64) k_tr_hash_coop(PoseidonDev P, TrJob J, con
     if (lane == 0) stg(out + i, s);
 }
 
+// Up to 4 independent long sponges in ONE launch (one block each): the four column chains of build_f0.
+struct TrMultiJob { const fr_t* prefix[4]; int np[4]; const fr_t* suffix[4]; int ns[4]; const fr_t* fields[4]; size_t k[4]; fr_t cap; };
+__global__ void __launch_bounds__(64) k_tr_hash_coop_multi(PoseidonDev P, TrMultiJob J, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    CoopLds L = coop_setup<17>(lds, P);
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const fr_t* prefix = J.prefix[b]; const fr_t* suffix = J.suffix[b]; const fr_t* fields = J.fields[b];
+    const size_t np = J.np[b], kk = J.k[b], total = np + kk + (size_t)J.ns[b];
+    fr_t s = lane == 16 ? J.cap : fr_zero<PF>();
+    for (size_t base = 0; base < total; base += 16) {
+        if (base) s = coop_permute<17>(s, P, L, lane);
+        const size_t e = base + lane;
+        if (lane < 16 && e < total) s = fr_add<PF>(s, e < np ? ldg(prefix + e) : (e < np + kk ? ldg(fields + (e - np)) : ldg(suffix + (e - np - kk))));
+    }
+    s = coop_permute<17>(s, P, L, lane);
+    if (lane == 0) stg(out + b, s);
+}
+
 // One Merkle node per wave (small levels: latency matters, not throughput).  Same job as k_hash_ds.
 template <int T>
 __global__ void __launch_bounds__(64) k_hash_ds_coop(PoseidonDev P, DsJob J, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
