@@ -360,3 +360,78 @@ def test_fold_and_ntt_properties_at_full_size(gpu_ctx, oracle):
     c = np.tile(oracle.from_u64(3), (n, 1))
     yc = gpu_ctx.fft(c, field=PALLAS_FR)
     assert (yc[0] == oracle.from_u64(3 * n)).all() and not yc[1:].any()
+
+
+# ---- remaining shapes of the reference's presets and edge cases ------------------------------------------------
+@pytest.mark.parametrize("arity,n", [(64, 4096), (128, 1 << 14), (64, 70), (128, 200)])
+def test_merkle_wide_arities(gpu_ctx, oracle, arity, n):
+    """arity 64 / 128 (t = 65 / 129, bench presets uni64x2x8, uni128...): rows longer than one wide chunk."""
+    leaves = oracle.synth_column(31, 3, 0, n)
+    t = gpu_ctx.merkle_new(leaves, gpu_ctx.merkle_cfg(arity, 2))
+    o = oracle.merkle_build(arity, 2, leaves)
+    assert t.num_levels == o.num_levels()
+    for lvl in range(t.num_levels):
+        assert (t.level(lvl) == o.level(lvl)).all()
+    t.free(); o.free()
+
+
+@pytest.mark.parametrize("n0,sched,r", [(16, [16], 3), (64, [8, 8], 4), (2, [2], 1), (1 << 12, [64, 64], 6)])
+def test_prove_degenerate_and_preset_shapes(gpu_ctx, oracle, n0, sched, r):
+    """last layer of a single element (arity 1 pair tree), tiny domains, and a 64-ary preset."""
+    f0 = oracle.synth_column(41, 0, 0, n0)
+    got, est, _ = gpu_ctx.deep_fri_prove(None, None, None, None, n0, DeepFriParams(sched, r, 0xDEEFBAAD), f0=f0)
+    ref = oracle.deep_fri_prove(None, None, None, None, n0, sched, r, 0xDEEFBAAD, f0=f0)
+    assert got == ref.bytes() and est == ref.size_estimate()
+    assert oracle.deep_fri_verify(got, sched, r, 0xDEEFBAAD) == 1
+    ref.free()
+    with pytest.raises(StarkError):
+        gpu_ctx.deep_fri_prove(None, None, None, None, n0, DeepFriParams([3], r, 1), f0=f0)       # schedule not dividing the domain
+    with pytest.raises(StarkError):
+        gpu_ctx.deep_fri_prove(None, None, None, None, 24, DeepFriParams([2], r, 1), f0=oracle.synth_column(1, 0, 0, 24))   # not a radix-2 domain
+
+
+def test_bench_step_shape_against_oracle(gpu_ctx, oracle):
+    """The bench workload at a size the oracle finishes in seconds: LDE of 4 columns (blow-up 8, shift 5),
+    DEEP-ALI merge with a fixed z, fri_build_transcript [16,16,8] — every root identical."""
+    lg, lb = 8, 3
+    n, N = 1 << lg, 1 << (lg + lb)
+    cols = [oracle.synth_column(0x5EED0000 + lg, c, 0, n) for c in range(4)]
+    g, z, omega = oracle.from_u64(5), oracle.from_u64(0xC0FFEE), oracle.root_of_unity(lg + lb)
+    ext_g = [gpu_ctx.lde(c, lb, field=PALLAS_FR, coset=g) for c in cols]
+    ext_o = [oracle.lde(0, c, lb, g) for c in cols]
+    for a, b in zip(ext_g, ext_o):
+        assert (a == b).all()
+    f0_g, _, _ = gpu_ctx.deep_ali_merge_evals(ext_g[0], ext_g[1], ext_g[2], ext_g[3], omega, z, want_c_star=False)
+    f0_o, _ = oracle.ali_merge(ext_o[0], ext_o[1], ext_o[2], ext_o[3], omega, z, want_c_star=False)
+    assert (f0_g == f0_o).all()
+    st = gpu_ctx.fri_build_transcript(f0_g, [16, 16, 8], 0xDEEFBAAD)
+    ref = oracle.deep_fri_prove(None, None, None, None, N, [16, 16, 8], 1, 0xDEEFBAAD, f0=f0_o)
+    for l in range(4):
+        assert (st.root(l) == ref.root(l)).all()
+    st.free(); ref.free()
+
+
+def test_commitment_adapter_and_legacy_prover(gpu_ctx, oracle):
+    """commitment/src/lib.rs:80-114 MerkleCommitment::commit: arity 16, params "POSEIDON-T17-X5-SEED",
+    tree_label = ds_tag (test :121-136: seed 42, n = 64, ds_tag 123)."""
+    from stark_mlwe_amd.api import MerkleChannelCfg
+    leaves = oracle.rand_fr_columns(42, 64)[0]
+    p = gpu_ctx.generate_params_t17_x5(b"POSEIDON-T17-X5-SEED")
+    t = gpu_ctx.merkle_new(leaves, MerkleChannelCfg(16, p, 123))
+    o = oracle.merkle_build(16, 123, leaves, params_kind=2)
+    assert (t.root() == o.root()).all() and (t.level(1) == o.level(1)).all()
+    assert o.open_verify([0, 15, 16, 31, 47, 63], leaves[[0, 15, 16, 31, 47, 63]])[0] == 1
+    t.free(); o.free(); p.free()
+
+
+def test_ntt_2pow24_device_properties(gpu_ctx, oracle):
+    """BASELINE size 2^24 (three-pass plan): round trip and closed-form spectra, no oracle needed."""
+    n = 1 << 24
+    x = oracle.synth_column(24, 7, 0, n)
+    y = gpu_ctx.fft(x, field=PALLAS_FR)
+    assert (gpu_ctx.ifft(y, field=PALLAS_FR) == x).all()
+    d = np.zeros((n, 4), np.uint64); d[3] = oracle.from_u64(1)          # delta at j = 3  ->  X[k] = w^(3k)
+    yd = gpu_ctx.fft(d, field=PALLAS_FR)
+    w = oracle.root_of_unity(24); w3 = oracle.mul(oracle.mul(w, w), w)
+    assert (yd[0] == oracle.from_u64(1)).all() and (yd[1] == w3).all() and (yd[n // 2] == oracle.pow(w3, n // 2)).all()
+    assert (yd[n - 1] == oracle.pow(w3, n - 1)).all()

@@ -5,6 +5,8 @@ mkdir -p gpurun_out
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 R=${1:-r01}
+mkdir -p tools/bin
+[ -x tools/bin/instr_rates ] || hipcc --offload-arch=gfx950 -O3 tools/instr_rates.hip -o tools/bin/instr_rates
 timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_$R.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/gpu_tests_$R.log
 tail -3 gpurun_out/gpu_tests_$R.log
 timeout -k 10 120 ./tools/bin/instr_rates > gpurun_out/instr_rates_$R.jsonl 2>&1 && echo "instr_rates done" &&
