@@ -1,6 +1,7 @@
 // stark_mlwe_amd/csrc/capi_ntt.hip — NTT / iNTT / LDE entry points and plans (crates/fft/src/lib.rs:6-32),
 // the per-GPU building blocks of the multi-GPU six-step NTT, and the synthetic-input generator.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "ctx.hpp"
 #include "fri_dev.hpp"
@@ -67,14 +68,20 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
 }
 
 static inline size_t ntt_lds_bytes(int log_b, int log_c) { return (((size_t)2 << (log_b + log_c)) + ((size_t)1 << log_b)) * 16; }
-static inline int pick_log_c(int log_b, int cap) { int lc = log_b >= 10 ? 2 : std::max(2, 11 - log_b); return std::max(0, std::min(lc, cap)); }
+// one workgroup per CU (tile > 80 KiB of LDS) => 512 threads so that every SIMD still holds 2 waves
+static inline unsigned ntt_threads(size_t lds) { return lds > 80 * 1024 ? 512u : 256u; }
+// tile elements E = B*C: 2^11 by default (64 KiB + twiddles => 2 workgroups per CU); STARK_NTT_LOG_E overrides for tuning
+static inline int ntt_log_e() { static const int v = [] { const char* e = getenv("STARK_NTT_LOG_E"); int x = e ? atoi(e) : 11; return x < 8 ? 8 : (x > 12 ? 12 : x); }(); return v; }
+static inline int ntt_minw() { static const int v = [] { const char* e = getenv("STARK_NTT_MINW"); return e ? atoi(e) : 2; }(); return v; }
+static inline int pick_log_c(int log_b, int cap) { int lc = std::max(2, ntt_log_e() - log_b); return std::max(0, std::min(lc, cap)); }
 
 template <class F>
 static int32_t launch_strided(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, const fr_t* src, fr_t* dst) {
     size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
     if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
     uint64_t tiles = total_elems >> (A.log_b + A.log_c);
-    hipLaunchKernelGGL(k_ntt_strided<F>, dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    if (ntt_minw() > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_strided<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    else hipLaunchKernelGGL((k_ntt_strided<F, 2>), dim3((unsigned)tiles), dim3(ntt_threads(lds)), lds, ctx->stream, A, src, dst);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
 template <class F>
@@ -82,7 +89,8 @@ static int32_t launch_last(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, 
     size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
     if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
     uint64_t tiles = total_elems >> (A.log_b + A.log_c);
-    hipLaunchKernelGGL(k_ntt_last<F>, dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    if (ntt_minw() > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_last<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    else hipLaunchKernelGGL((k_ntt_last<F, 2>), dim3((unsigned)tiles), dim3(ntt_threads(lds)), lds, ctx->stream, A, src, dst);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
 
@@ -143,10 +151,10 @@ void stark::ntt_plans_free(stark_ctx* ctx) { for (auto& kv : ctx->plans) delete 
 
 static void set_ntt_attrs() {
     static bool done = false; if (done) return; done = true;
-    (void)hipFuncSetAttribute((const void*)k_ntt_strided<PallasFr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_ntt_last<PallasFr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_ntt_strided<Bls12381Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_ntt_last<Bls12381Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided<PallasFr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_last<PallasFr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided<Bls12381Fr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_last<Bls12381Fr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
 }
 
 // Multi-GPU phase A: column NTTs of size 2^log_rows over a row-major [2^log_rows][ncols] slab whose first

@@ -142,8 +142,8 @@ __device__ __forceinline__ void tail_store(const NttPassArgs& A, const uint4* dl
 }
 
 // Strided pass.  grid.x = (n / (B*S)) * (S / C) tiles.
-template <class F>
-__global__ void __launch_bounds__(256) k_ntt_strided(NttPassArgs A, const fr_t* src, fr_t* dst) {
+template <class F, int MINW>
+__global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttPassArgs A, const fr_t* src, fr_t* dst) {
     extern __shared__ uint4 lds[];
     const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c;
     uint4 *dlo = lds, *dhi = lds + E, *tlo = lds + 2 * E, *thi = tlo + (B >> 1);
@@ -168,8 +168,8 @@ __global__ void __launch_bounds__(256) k_ntt_strided(NttPassArgs A, const fr_t* 
 }
 
 // Last (contiguous) pass with the digit-reversing store.  grid.x = n / (B*C) tiles.
-template <class F>
-__global__ void __launch_bounds__(256) k_ntt_last(NttPassArgs A, const fr_t* src, fr_t* dst) {
+template <class F, int MINW>
+__global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_last(NttPassArgs A, const fr_t* src, fr_t* dst) {
     extern __shared__ uint4 lds[];
     const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c;
     uint4 *dlo = lds, *dhi = lds + E, *tlo = lds + 2 * E, *thi = tlo + (B >> 1);
