@@ -73,7 +73,11 @@ static inline unsigned ntt_threads(size_t lds) { return lds > 80 * 1024 ? 512u :
 // tile elements E = B*C: 2^11 by default (64 KiB + twiddles => 2 workgroups per CU); STARK_NTT_LOG_E overrides for tuning
 static inline int ntt_log_e() { static const int v = [] { const char* e = getenv("STARK_NTT_LOG_E"); int x = e ? atoi(e) : 11; return x < 8 ? 8 : (x > 12 ? 12 : x); }(); return v; }
 static inline int ntt_minw() { static const int v = [] { const char* e = getenv("STARK_NTT_MINW"); return e ? atoi(e) : 2; }(); return v; }
-static inline int pick_log_c(int log_b, int cap) { int lc = std::max(2, ntt_log_e() - log_b); return std::max(0, std::min(lc, cap)); }
+// total_log: log2 of all elements the launch covers; small launches take smaller tiles so that the grid still fills the chip
+static inline int pick_log_c(int log_b, int cap, int total_log = 30) {
+    int le = ntt_log_e(); if (!getenv("STARK_NTT_LOG_E") && total_log - le < 9) le = std::max(8, std::min(le, total_log - 8));
+    int lc = std::max(2, le - log_b); return std::max(0, std::min(lc, cap));
+}
 
 template <class F>
 static int32_t launch_strided(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, const fr_t* src, fr_t* dst) {
@@ -123,7 +127,7 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     int rem = log_n;                       // log2 of the current sub-problem size
     for (int i = 0; i + 1 < p->P; ++i) {   // strided passes
         A.log_b = p->log_b[i]; A.log_m = rem; A.stride = 1ull << (rem - A.log_b);
-        A.log_c = pick_log_c(A.log_b, rem - A.log_b);
+        A.log_c = pick_log_c(A.log_b, rem - A.log_b, log_n);
         A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none;
         STARK_TRY(launch_strided<F>(ctx, A, total, src, scratch));
         src = scratch; rem -= A.log_b;
@@ -131,7 +135,7 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     A.pre = (p->P == 1) ? pre : none;
     A.log_b = p->log_b[p->P - 1]; A.stage_tw = p->stage_tw[p->P - 1];
     A.log_b1 = p->P >= 2 ? p->log_b[0] : 0; A.log_b2 = p->P == 3 ? p->log_b[1] : 0;
-    A.log_c = p->P == 1 ? 0 : pick_log_c(A.log_b, A.log_b1);
+    A.log_c = p->P == 1 ? 0 : pick_log_c(A.log_b, A.log_b1, log_n);
     A.post = post; A.scale = post.lo ? nullptr : (scale_override_dev ? scale_override_dev : (inverse ? p->scale : nullptr));
     STARK_TRY(launch_last<F>(ctx, A, total, src, data));
     return STARK_OK;
