@@ -44,6 +44,16 @@ def main():
         ctx._chk(lib.stark_synth_column_dev(ctx.h, 1, 0, 0, n, C.c_void_p(f.data_ptr())))
         ms = timed(lambda: ctx._chk(lib.stark_tr_hash_fields_tagged_dev(ctx.h, None, b"ALI/A", C.c_void_p(f.data_ptr()), n, 1, C.c_void_p(o.data_ptr()))), reps=1)
         print(json.dumps({"kernel": "column_sponge", "log_n": lg, "ms": ms, "us_per_permutation": ms * 1e3 / (n / 16)}), flush=True)
+    # six-step building blocks on one GPU (world size 1): column pass + (identity exchange) + row pass
+    from stark_mlwe_amd import dist as sd
+    for lg, lr in ((20, 10), (24, 10)):
+        slab = dbuf(1 << lg); ctx._chk(lib.stark_synth_column_dev(ctx.h, 1, 7, 0, 1 << lg, C.c_void_p(slab.data_ptr())))
+        plan = sd.DistNtt(sd.HipProvider(ctx), lg, lr)
+        def run():
+            plan.p.ntt_columns(slab, plan.log_rows, plan.ncl, 0, lg, False); plan.p.ntt_rows(slab, plan.nrl, lg - lr, False, None)
+        ms = timed(run)
+        print(json.dumps({"kernel": "six_step_local_phases", "log_n": lg, "log_rows": lr, "ms": ms, "GBps": 64.0 * (1 << lg) / ms / 1e6}), flush=True)
+        del slab
     ctx.close()
 
 
