@@ -36,15 +36,18 @@ def exchange_all_to_all(send: torch.Tensor) -> torch.Tensor:
     if dist.get_backend() == "nccl":
         dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1))     # RCCL: one message per peer link
         return recv
-    # gloo has no all_to_all: W-1 point-to-point pairs (CPU tests only)
-    recv[rank].copy_(send[rank])
+    # gloo has no all_to_all: W-1 point-to-point pairs, staged through host memory (tests / one-GPU rehearsal only)
+    hs = send.cpu() if send.is_cuda else send
+    hr = torch.empty_like(hs)
+    hr[rank].copy_(hs[rank])
     ops = []
     for p in range(W):
         if p != rank:
-            ops.append(dist.P2POp(dist.isend, send[p].contiguous(), p))
-            ops.append(dist.P2POp(dist.irecv, recv[p], p))
+            ops.append(dist.P2POp(dist.isend, hs[p].contiguous(), p))
+            ops.append(dist.P2POp(dist.irecv, hr[p], p))
     for r in dist.batch_isend_irecv(ops):
         r.wait()
+    recv.copy_(hr)
     return recv
 
 
@@ -52,6 +55,10 @@ def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
     rank, W = world()
     if W == 1:
         return x.clone()
+    if dist.get_backend() != "nccl" and x.is_cuda:     # gloo: stage through host memory
+        hx = x.cpu(); out = [torch.empty_like(hx) for _ in range(W)]
+        dist.all_gather(out, hx.contiguous())
+        return torch.cat(out, dim=0).to(x.device)
     out = [torch.empty_like(x) for _ in range(W)]
     dist.all_gather(out, x.contiguous())
     return torch.cat(out, dim=0)

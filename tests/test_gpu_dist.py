@@ -1,0 +1,56 @@
+"""Two ranks sharing ONE MI355X (gloo for the exchange, staged through host memory): the product kernels in
+a real 2-way decomposition — non-zero global column offsets in the six-step NTT, global DS positions in
+the sharded Merkle tree — against the oracle.  The 8-GPU RCCL run itself is the driver's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, log_n, log_rows, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib
+        from stark_mlwe_amd import dist as sd
+        from stark_mlwe_amd.api import Context
+        torch.cuda.set_device(0)
+        ctx = Context(0); o = oracle_lib.Oracle(); prov = sd.HipProvider(ctx)
+        n = 1 << log_n
+        x = o.synth_column(77, 7, 0, n)
+        want = o.ntt(0, x)
+        plan = sd.DistNtt(prov, log_n, log_rows)
+        slab = torch.from_numpy(x[plan.local_input_indices().reshape(-1).numpy()].view(np.int64).copy()).cuda()
+        rows = plan.forward(slab); ctx.sync()
+        ok_t = bool((rows.cpu().numpy().view(np.uint64) == want[plan.local_output_indices().reshape(-1).numpy()]).all())
+        nat = plan.to_natural_blocks(rows).cpu().numpy().view(np.uint64)
+        ok_n = bool((nat == want[rank * n // world:(rank + 1) * n // world]).all())
+        leaves = o.synth_column(5, 1, 0, 1 << 13)
+        half = (1 << 13) // world
+        mine = torch.from_numpy(leaves[rank * half:(rank + 1) * half].view(np.int64).copy()).cuda()
+        root = sd.merkle_sharded_root(prov, ctx.poseidon_params_for_width(17), 16, 9, mine, half)
+        ok_m = bool((root.cpu().numpy().view(np.uint64) == o.merkle_build(16, 9, leaves).root()).all())
+        ctx.close()
+        q.put((rank, ok_t, ok_n, ok_m))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("log_n,log_rows", [(14, 7), (20, 10)])
+def test_two_ranks_share_one_gpu(log_n, log_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000) + log_n
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, log_n, log_rows, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs: p.join(120)
+    assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
