@@ -158,6 +158,31 @@ def main():
     prove_e2e = prove(16, False)                       # DeepAliRealBuilder incl. the four serial column sponges
     prove_f0 = prove(20, True)                         # "prove given f0": everything after build_f0
 
+    # ---- the one real exchange of the path: six-step NTT of ONE 2^24 vector sharded over all ranks (config[3]) ----
+    # Reported beside the main line, never part of `value`; a failure here must not take the bench line down.
+    dist_ntt = None
+    try:
+        from stark_mlwe_amd import dist as sd
+        lgd = 24
+        plan = sd.DistNtt(sd.HipProvider(ctx, device=dev), lgd, 10)
+        slab = dbuf((1 << lgd) // world)
+        ctx._chk(lib.stark_synth_column_dev(ctx.h, seed, 7, rank * ((1 << lgd) // world), (1 << lgd) // world, C.c_void_p(slab.data_ptr())))
+        plan.forward(slab); barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            plan.forward(slab)
+        barrier()
+        dt = (time.perf_counter() - t1) / 3
+        if world > 1:
+            tm = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX); dt = float(tm.item())
+        dist_ntt = {"log_n": lgd, "ranks": world, "ms": dt * 1e3, "GBps_algorithmic": 64.0 * (1 << lgd) / dt / 1e9,
+                    "all_to_all_bytes_per_rank": (1 << lgd) * 32 // world * (world - 1) // world,
+                    "note": "column NTTs + twiddle, one all_to_all_single over RCCL, row NTTs; output in transposed block order"}
+        del slab
+    except Exception as ex:   # noqa: BLE001
+        dist_ntt = {"error": repr(ex)[:300]}
+
     out = None
     if rank == 0:
         traffic = None
@@ -186,6 +211,7 @@ def main():
                          "reference_dense_fr_mults_per_s": FR_MULTS_T17 * N / (leaf_ms * 1e-3), "bound": "integer VALU (not HBM, not MFMA)"},
             "prove_end_to_end": dict(prove_e2e, note="deep_fri_prove with DeepAliRealBuilder on a 2^16-row trace (device-resident columns); build_f0 is the serial column sponge (fri.rs:548-557)"),
             "prove_given_f0": dict(prove_f0, note="deep_fri_prove stages after build_f0 on n0 = 2^20"),
+            "dist_ntt": dist_ntt,
             "roots": ["".join(f"{int(x):016x}" for x in r[::-1]) for r in roots],
         }
         if not args.no_cpu_baseline and world == 1:
