@@ -17,7 +17,7 @@ static const size_t kMaxLds = 160 * 1024;
 static inline int poseidon_block(int t) { return (size_t)t * 32 * 64 <= kMaxLds ? 64 : 32; }
 static inline size_t poseidon_lds(int t, int block) { return (size_t)t * 32 * block; }
 // the wave-pair kernels (poseidon_pair.hpp) serve the hot widths; STARK_POSEIDON_IMPL=lane selects the one-lane-per-sponge form
-static inline bool use_pair(int t) { static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }(); return !lane_only && t <= 17; }
+static inline bool use_pair(int t) { static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }(); return !lane_only && (t == 9 || t == 17); }
 
 namespace stark {
 
@@ -35,13 +35,13 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     if (!P->kc.ok) return ctx->fail(STARK_ERR_UNSUPPORTED, "MDS matrix has a singular leading minor: LU/sparse kernel form unavailable");
     const host::KernelConsts& k = P->kc;
     std::vector<fr_t> blob; auto put = [&](const std::vector<fr_t>& v) { size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
-    size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds), o_mpre = put(k.mds_pre);
+    size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds), o_mpre = put(k.mds_pre), o_gam = put(k.gamma);
     STARK_HIP(ctx, hipMalloc((void**)&P->blob, blob.size() * sizeof(fr_t)));
     STARK_HIP(ctx, hipMemcpyAsync(P->blob, blob.data(), blob.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     P->dev.t = k.t; P->dev.rf = k.rf; P->dev.rp = k.rp;
     P->dev.rc_full = P->blob + o_rcf; P->dev.rc_partial = P->blob + o_rcp; P->dev.lu = P->blob + o_lu; P->dev.lu_pre = P->blob + o_pre;
-    P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds; P->dev.mds_pre = P->blob + o_mpre;
+    P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds; P->dev.mds_pre = P->blob + o_mpre; P->dev.gamma = P->blob + o_gam;
     return STARK_OK;
 }
 static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c, stark_params** out) {
@@ -171,7 +171,8 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     (void)hipFuncSetAttribute((const void*)k_tr_hash, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_hash_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_leaf_pair2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_hash_ds2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_hash_ds2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_hash_ds2<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     *out = c; return STARK_OK;
 }
 int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
@@ -280,7 +281,8 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, stark_params_t* p, int mode, siz
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     if (use_pair(p->dev.t)) {
-        hipLaunchKernelGGL(k_hash_ds2, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(p->dev.t), ctx->stream, p->dev, J, in0, in1, out);
+        if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds2<17>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(17), ctx->stream, p->dev, J, in0, in1, out);
+        else hipLaunchKernelGGL(k_hash_ds2<9>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(9), ctx->stream, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     const int block = poseidon_block(p->dev.t);

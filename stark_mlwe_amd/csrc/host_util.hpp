@@ -197,6 +197,7 @@ struct KernelConsts {
     std::vector<fr_t> sparse;           // rp*(2t-1): [a, u_1..u_{t-1}, w_1..w_{t-1}] in application order
     std::vector<fr_t> mds;              // t*t reference form (cooperative kernel: full rounds)
     std::vector<fr_t> mds_pre;          // t*t dense B_1*M (cooperative kernel: last first-half full round)
+    std::vector<fr_t> gamma;            // (rp/4)*6: blocks of 4 partial rounds, gamma[q(q-1)/2+p] = sum_j u_{q,j} w_{p,j} (p < q)
     bool ok = false;
 };
 // Gauss-Jordan inverse of an n x n matrix (row-major); returns false when singular.
@@ -249,6 +250,19 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
         cur.swap(nxt);
     }
     // cur == B_1 * M == mds_pre
+    // Blocks of 4 partial rounds: within a block the lanes 1..t-1 are read at their block-start value and
+    // the S-box outputs x_p enter later rounds through gamma_{q,p} = sum_j u_{q,j} * w_{p,j}  (p < q).
+    if (c.rp % 4) return k;
+    k.gamma.assign((size_t)(c.rp / 4) * 6, h_zero());
+    for (int b = 0; b < c.rp / 4; ++b)
+        for (int q = 1; q < 4; ++q)
+            for (int p2 = 0; p2 < q; ++p2) {
+                const fr_t* uq = &k.sparse[(size_t)(4 * b + q) * (2 * t - 1)];
+                const fr_t* wp = &k.sparse[(size_t)(4 * b + p2) * (2 * t - 1)];
+                fr_t acc = h_zero();
+                for (int j = 1; j < t; ++j) acc = h_add(acc, h_mul(uq[j], wp[t - 1 + j]));
+                k.gamma[(size_t)b * 6 + q * (q - 1) / 2 + p2] = acc;
+            }
     if (!lu_pack(c.mds, t, k.lu)) return k;
     if (!lu_pack(cur, t, k.lu_pre)) return k;
     k.mds_pre = cur;

@@ -5,14 +5,18 @@
 // VALU instruction only every ~5 cycles (measured: v_mad_u64_u32 11.0 vs 5.4 cycles/instr at 1 vs 2
 // waves per SIMD).  Here a workgroup is a pair of waves (X, Y) that share the 64 LDS-resident states of
 // the batch: lane l of both waves works on state l, each wave on its own part of the linear algebra.
-// Same LDS per state, twice the waves per SIMD.
+// Same LDS per state, twice the waves per SIMD (4 workgroups of 40 KiB per CU for t = 17).
 //   * full rounds : S-box on the wave's own elements; the dense MDS as in-place L*(U*x), X taking the
 //                   even rows and Y the odd rows of each step (rows 2k/2k+1 read only slots >= 2k, so a
 //                   single barrier between the step's reads and its two writes keeps it race-free);
-//   * partial rounds (sparse form): X owns lanes 0..nx-1 incl. the S-box lane, Y the rest.  Y computes
-//                   its share sum_{j>=nx} u_j s_j of the NEXT round's dot product while X runs the
-//                   S-box, so the two waves are balanced; the hand-offs (s0 from X, partial dot from Y)
-//                   go through one LDS slot each, bracketed by two back-to-back barriers per round.
+//   * partial rounds, in blocks of 4 (see permute_core in poseidon_dev.hpp for the algebra):
+//       phase 1  X runs the S-box chain: x_q, then a_q x_q + sum_{p<q} gamma x_p + its quarter of the
+//                lane dot product from registers; Y computes the other three quarters of every round's
+//                dot product from the block-start state and posts it in an LDS mailbox (one barrier per round);
+//       phase 2  both waves bring their half of the lanes up to date, s_j += sum_p w_{p,j} x_p (one
+//                reduction per lane), X from registers, Y from the x mailboxes.
+//     The mailboxes reuse state slots that are dead during the block (slot 0: X holds s0 in registers;
+//     slots 1..NXD: X preloads those lanes), so the LDS budget stays at 4 workgroups per CU.
 // Results are the same field values as poseidon_dev.hpp / the reference's dense rounds.
 #pragma once
 #include "fr.hpp"
@@ -23,140 +27,182 @@
 #if defined(__HIPCC__)
 namespace stark {
 
+template <int T> struct PairCfg {
+    static constexpr int NXD = (T - 1) / 4;            // X's share of the lanes in the per-round dot products: lanes 1..NXD
+    static constexpr int NXU = (T - 1) / 2;            // X updates lanes 1..NXU, Y lanes NXU+1..T-1
+    static constexpr int NX = (T - 1) / 2;             // full rounds: X owns elements 0..NX-1 (S-box, absorb), Y the rest
+    static constexpr int EXTRA = 3 + (NXD < 4 ? 4 - NXD : 0);   // slots beyond the state: x mailboxes 1..3 + the Dy mailboxes that cannot alias
+    __host__ __device__ static constexpr int xslot(int p) { return p == 0 ? 0 : T + (p - 1); }
+    __host__ __device__ static constexpr int dslot(int q) { return q < NXD ? 1 + q : T + 3 + (q - NXD); }
+    __host__ __device__ static constexpr size_t lds_bytes() { return (size_t)(T + EXTRA) * 2 * 64 * 16; }
+};
+static inline size_t pair_lds_bytes(int t) { return t == 17 ? PairCfg<17>::lds_bytes() : PairCfg<9>::lds_bytes(); }
+
 struct PairState {
-    uint4* st;      // [t][2][64]
-    uint4* xs0;     // [2][64]  X -> Y : s0 after the S-box (one slot)
-    uint4* xdot;    // [2][64]  Y -> X : Y's share of the dot product (one slot)
-    int lane; bool isY; int nx;
-    __device__ __forceinline__ static fr_t rd(const uint4* base, int slot, int lane) {
-        uint4 lo = base[(2 * slot) * 64 + lane], hi = base[(2 * slot + 1) * 64 + lane];
+    uint4* st;      // [T + EXTRA][2][64]
+    int lane; bool isY;
+    __device__ __forceinline__ fr_t ld(int j) const {
+        uint4 lo = st[(2 * j) * 64 + lane], hi = st[(2 * j + 1) * 64 + lane];
         fr_t x; x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w; return x;
     }
-    __device__ __forceinline__ static void wr(uint4* base, int slot, int lane, const fr_t& x) {
-        base[(2 * slot) * 64 + lane] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-        base[(2 * slot + 1) * 64 + lane] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    __device__ __forceinline__ void sto(int j, const fr_t& x) const {
+        st[(2 * j) * 64 + lane] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        st[(2 * j + 1) * 64 + lane] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
     }
-    __device__ __forceinline__ fr_t ld(int j) const { return rd(st, j, lane); }
-    __device__ __forceinline__ void sto(int j, const fr_t& x) const { wr(st, j, lane, x); }
-    __device__ __forceinline__ bool owns(int j) const { return isY ? j >= nx : j < nx; }
 };
-static inline size_t pair_lds_bytes(int t) { return ((size_t)t * 2 * 64 + 2 * 2 * 64) * 16; }
 
-// In-place y = L*(U*x) over the shared state; one barrier per step (see header comment).  Ends with the
-// state consistent for both waves.
-__device__ __forceinline__ void pair_apply_lu(const PairState& s, const fr_t* lu, int t) {
+// In-place y = L*(U*x) over the shared state; one barrier per step.  Ends with the state consistent.
+template <int T>
+__device__ __forceinline__ void pair_apply_lu(const PairState& s, const fr_t* lu) {
     const int yo = s.isY ? 1 : 0;
-    for (int k = 0; 2 * k < t; ++k) {                       // U, top-down: rows 2k (X) and 2k+1 (Y)
-        const int i = 2 * k + yo; const bool have = i < t;
+    for (int k = 0; 2 * k < T; ++k) {                       // U, top-down: rows 2k (X) and 2k+1 (Y)
+        const int i = 2 * k + yo; const bool have = i < T;
         fr_t res;
-        if (have) { fr_wide w; fr_wide_zero(w); for (int j = i; j < t; ++j) fr_wide_mac_f<PF>(w, lu[i * t + j], s.ld(j)); res = fr_wide_reduce<PF>(w); }
+        if (have) { fr_wide w; fr_wide_zero(w); for (int j = i; j < T; ++j) fr_wide_mac_f<PF>(w, lu[i * T + j], s.ld(j)); res = fr_wide_reduce<PF>(w); }
         __syncthreads();
         if (have) s.sto(i, res);
     }
     __syncthreads();
-    for (int k = 0; t - 1 - 2 * k >= 1; ++k) {              // unit-lower L, bottom-up: rows t-1-2k (X) and t-2-2k (Y)
-        const int i = t - 1 - 2 * k - yo; const bool have = i >= 1;
+    for (int k = 0; T - 1 - 2 * k >= 1; ++k) {              // unit-lower L, bottom-up: rows T-1-2k (X) and T-2-2k (Y)
+        const int i = T - 1 - 2 * k - yo; const bool have = i >= 1;
         fr_t res;
-        if (have) { fr_wide w; fr_wide_zero(w); for (int j = 0; j < i; ++j) fr_wide_mac_f<PF>(w, lu[i * t + j], s.ld(j)); res = fr_add<PF>(s.ld(i), fr_wide_reduce<PF>(w)); }
+        if (have) { fr_wide w; fr_wide_zero(w); for (int j = 0; j < i; ++j) fr_wide_mac_f<PF>(w, lu[i * T + j], s.ld(j)); res = fr_add<PF>(s.ld(i), fr_wide_reduce<PF>(w)); }
         __syncthreads();
         if (have) s.sto(i, res);
     }
     __syncthreads();
 }
-__device__ __forceinline__ void pair_sbox_full(const PairState& s, const fr_t* rc, int t) {
-    const int j0 = s.isY ? s.nx : 0, j1 = s.isY ? t : s.nx;
+template <int T>
+__device__ __forceinline__ void pair_sbox_full(const PairState& s, const fr_t* rc) {
+    const int j0 = s.isY ? PairCfg<T>::NX : 0, j1 = s.isY ? T : PairCfg<T>::NX;
     for (int j = j0; j < j1; ++j) s.sto(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), rc[j])));
     __syncthreads();
 }
-// Y's share of a partial round's dot product: sum_{j>=nx} u_j s_j.
-__device__ __forceinline__ fr_t pair_dot_y(const PairState& s, const fr_t* sp, int t) {
-    fr_wide w; fr_wide_zero(w);
-    for (int j = s.nx; j < t; ++j) fr_wide_mac_f<PF>(w, sp[j], s.ld(j));
-    return fr_wide_reduce<PF>(w);
+
+// s_j += w_{0,j} x0 + w_{1,j} x1 + w_{2,j} x2 + w_{3,j} x3   (one reduction)
+template <int T>
+__device__ __forceinline__ fr_t pair_lane_update(const fr_t* sp, int j, const fr_t& base, const fr_t& x0, const fr_t& x1, const fr_t& x2, const fr_t& x3) {
+    constexpr int W = 2 * T - 1;
+    fr_wide u; fr_wide_zero(u);
+    fr_wide_mac_f<PF>(u, sp[0 * W + T - 1 + j], x0); fr_wide_mac_f<PF>(u, sp[1 * W + T - 1 + j], x1);
+    fr_wide_mac_f<PF>(u, sp[2 * W + T - 1 + j], x2); fr_wide_mac_f<PF>(u, sp[3 * W + T - 1 + j], x3);
+    return fr_add<PF>(base, fr_wide_reduce<PF>(u));
 }
+
 // One permutation by the wave pair.  Precondition: state consistent (a barrier since the last write).
 // Returns lane 0 of the result in BOTH waves; with only0 the rest of the state is dead afterwards.
+template <int T>
 __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonDev& P, bool only0, int r_begin = 0) {
-    const int t = P.t, half = P.rf / 2, w = 2 * t - 1;
+    typedef PairCfg<T> Cfg;
+    constexpr int NXD = Cfg::NXD, NXU = Cfg::NXU, W = 2 * T - 1;
+    const int half = P.rf / 2;
     for (int r = r_begin; r < half; ++r) {
-        pair_sbox_full(s, P.rc_full + r * t, t);
-        pair_apply_lu(s, (r == half - 1) ? P.lu_pre : P.lu, t);
+        pair_sbox_full<T>(s, P.rc_full + r * T);
+        pair_apply_lu<T>(s, (r == half - 1) ? P.lu_pre : P.lu);
     }
-    // Partial rounds.  Two barriers per round bracket the hand-off slots (A: published, B: consumed), so one
-    // slot each suffices (4 workgroups of 38.9 KB per CU = 2 waves per SIMD).
     fr_t s0 = fr_zero<PF>();
     if (!s.isY) s0 = s.ld(0);
-    else PairState::wr(s.xdot, 0, s.lane, pair_dot_y(s, P.sparse, t));
-    for (int r = 0; r < P.rp; ++r) {
-        const fr_t* sp = P.sparse + (size_t)r * w;
-        if (!s.isY) { s0 = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[r])); PairState::wr(s.xs0, 0, s.lane, s0); }
-        __syncthreads();                                                       // A_r
-        const fr_t got = s.isY ? PairState::rd(s.xs0, 0, s.lane) : PairState::rd(s.xdot, 0, s.lane);
-        __syncthreads();                                                       // B_r
+    for (int b = 0; b < P.rp / 4; ++b) {
+        const fr_t* sp = P.sparse + (size_t)(4 * b) * W;
+        const fr_t* g = P.gamma + (size_t)b * 6;
         if (!s.isY) {
-            fr_wide acc; fr_wide_zero(acc);
-            fr_wide_mac_f<PF>(acc, sp[0], s0);
-            for (int j = 1; j < s.nx; ++j) { fr_t sj = s.ld(j); fr_wide_mac_f<PF>(acc, sp[j], sj); s.sto(j, fr_add<PF>(sj, fr_mul<PF>(sp[t - 1 + j], s0))); }
-            s0 = fr_add<PF>(fr_wide_reduce<PF>(acc), got);
+            // ---- X: the S-box chain ------------------------------------------------------------------------
+            fr_t keep[NXD];
+#pragma unroll
+            for (int j = 0; j < NXD; ++j) keep[j] = s.ld(1 + j);      // their slots become Y's mailboxes for this block
+            __syncthreads();                                           // S: mailboxes may be written from here on
+            fr_t x0, x1, x2, x3;
+#define STARK_PAIR_ROUND(q, XQ)                                                                       \
+            {                                                                                         \
+                XQ = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                             \
+                s.sto(Cfg::xslot(q), XQ);                                                             \
+                fr_wide acc; fr_wide_zero(acc);                                                       \
+                fr_wide_mac_f<PF>(acc, sp[q * W], XQ);                                                \
+                if (q > 0) fr_wide_mac_f<PF>(acc, g[q * (q - 1) / 2 + 0], x0);                         \
+                if (q > 1) fr_wide_mac_f<PF>(acc, g[q * (q - 1) / 2 + 1], x1);                         \
+                if (q > 2) fr_wide_mac_f<PF>(acc, g[q * (q - 1) / 2 + 2], x2);                         \
+                _Pragma("unroll") for (int j = 0; j < NXD; ++j) fr_wide_mac_f<PF>(acc, sp[q * W + 1 + j], keep[j]); \
+                const fr_t part = fr_wide_reduce<PF>(acc);                                            \
+                __syncthreads();                                       /* barrier_q: Dy_q is posted */ \
+                s0 = fr_add<PF>(part, s.ld(Cfg::dslot(q)));                                           \
+            }
+            STARK_PAIR_ROUND(0, x0) STARK_PAIR_ROUND(1, x1) STARK_PAIR_ROUND(2, x2) STARK_PAIR_ROUND(3, x3)
+#undef STARK_PAIR_ROUND
+            // ---- X: lanes 1..NXU up to date -------------------------------------------------------------------
+#pragma unroll
+            for (int j = 1; j <= NXD; ++j) s.sto(j, pair_lane_update<T>(sp, j, keep[j - 1], x0, x1, x2, x3));
+            for (int j = NXD + 1; j <= NXU; ++j) s.sto(j, pair_lane_update<T>(sp, j, s.ld(j), x0, x1, x2, x3));
         } else {
-            for (int j = s.nx; j < t; ++j) { fr_t sj = s.ld(j); s.sto(j, fr_add<PF>(sj, fr_mul<PF>(sp[t - 1 + j], got))); }
-            if (r + 1 < P.rp) PairState::wr(s.xdot, 0, s.lane, pair_dot_y(s, sp + w, t));
+            // ---- Y: three quarters of every round's dot product, from the block-start state ----------------------
+            __syncthreads();                                           // S
+            for (int q = 0; q < 4; ++q) {
+                fr_wide acc; fr_wide_zero(acc);
+                for (int j = NXD + 1; j < T; ++j) fr_wide_mac_f<PF>(acc, sp[q * W + j], s.ld(j));
+                const fr_t dy = fr_wide_reduce<PF>(acc);
+                s.sto(Cfg::dslot(q), dy);
+                __syncthreads();                                       // barrier_q
+            }
+            // ---- Y: lanes NXU+1..T-1 up to date (x_0..x_3 were posted before barrier_0..3) ---------------------------
+            const fr_t x0 = s.ld(Cfg::xslot(0)), x1 = s.ld(Cfg::xslot(1)), x2 = s.ld(Cfg::xslot(2)), x3 = s.ld(Cfg::xslot(3));
+            for (int j = NXU + 1; j < T; ++j) s.sto(j, pair_lane_update<T>(sp, j, s.ld(j), x0, x1, x2, x3));
         }
+        __syncthreads();                                               // E: lanes 1..T-1 consistent, mailboxes free
     }
     if (!s.isY) s.sto(0, s0);
     __syncthreads();
     for (int r = half; r < P.rf; ++r) {
-        pair_sbox_full(s, P.rc_full + r * t, t);
+        pair_sbox_full<T>(s, P.rc_full + r * T);
         if (only0 && r == P.rf - 1) {                       // squeeze: row 0 only, split over the two waves
-            const int j0 = s.isY ? s.nx : 0, j1 = s.isY ? t : s.nx;
+            const int j0 = s.isY ? Cfg::NX : 0, j1 = s.isY ? T : Cfg::NX;
             fr_wide acc; fr_wide_zero(acc);
             for (int j = j0; j < j1; ++j) fr_wide_mac_f<PF>(acc, P.row0[j], s.ld(j));
-            PairState::wr(s.isY ? s.xdot : s.xs0, 0, s.lane, fr_wide_reduce<PF>(acc));
+            s.sto(T + (s.isY ? 1 : 0), fr_wide_reduce<PF>(acc));     // two of the extra slots: not part of the state
             __syncthreads();
-            fr_t out = fr_add<PF>(PairState::rd(s.xs0, 0, s.lane), PairState::rd(s.xdot, 0, s.lane));
+            fr_t out = fr_add<PF>(s.ld(T + 0), s.ld(T + 1));
             __syncthreads();                                 // the slots are reused by the next permutation
             return out;
         }
-        pair_apply_lu(s, P.lu, t);
+        pair_apply_lu<T>(s, P.lu);
     }
     return s.ld(0);
 }
 
-__device__ __forceinline__ PairState pair_setup(uint4* lds, int t) {
-    PairState s; s.st = lds; s.xs0 = lds + t * 2 * 64; s.xdot = s.xs0 + 2 * 64;
-    s.lane = threadIdx.x & 63; s.isY = threadIdx.x >= 64; s.nx = (t - 1) / 2;
+__device__ __forceinline__ PairState pair_setup(uint4* lds) {
+    PairState s; s.st = lds; s.lane = threadIdx.x & 63; s.isY = threadIdx.x >= 64;
     return s;
 }
 
 // K3 (pair form): h[i] = hash_leaf_pair(f[i], f_next[i/m] or 0).  Block = 128 threads = 64 states.
-__global__ void __launch_bounds__(128) k_leaf_pair2(PoseidonDev P, const fr_t* __restrict__ leafc, const fr_t* __restrict__ f,
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k_leaf_pair2(PoseidonDev P, const fr_t* __restrict__ leafc, const fr_t* __restrict__ f,
                                                     const fr_t* __restrict__ f_next, size_t n, size_t m, fr_t* __restrict__ h) {
     extern __shared__ uint4 lds[];
-    PairState s = pair_setup(lds, 17);
+    PairState s = pair_setup(lds);
     const size_t i = (size_t)blockIdx.x * 64 + s.lane; const bool live = i < n; const size_t ii = live ? i : n - 1;   // tail lanes recompute the last leaf
     // Round 0 in closed form: 15 of the 17 lanes of the transcript template are constants, so after ARK and
     // S-box the MDS output is  K_i + M[i][4]*x4 + M[i][5]*x5  with K precomputed on the host
     // (leafc = [K(17) | M[:,4](17) | M[:,5](17)]).  Both waves compute x4, x5; each fills its own lanes.
     const fr_t x4 = fr_pow5<PF>(fr_add<PF>(ldg(f + ii), P.rc_full[4]));
     const fr_t x5 = fr_pow5<PF>(fr_add<PF>(f_next ? ldg(f_next + ii / m) : fr_zero<PF>(), P.rc_full[5]));
-    const int j0 = s.isY ? s.nx : 0, j1 = s.isY ? 17 : s.nx;
+    const int j0 = s.isY ? PairCfg<17>::NX : 0, j1 = s.isY ? 17 : PairCfg<17>::NX;
     for (int j = j0; j < j1; ++j) {
         fr_wide w; fr_wide_zero(w);
         fr_wide_mac_f<PF>(w, leafc[17 + j], x4); fr_wide_mac_f<PF>(w, leafc[34 + j], x5);
         s.sto(j, fr_add<PF>(leafc[j], fr_wide_reduce<PF>(w)));
     }
     __syncthreads();
-    fr_t out = pair_permute(s, P, true, 1);
+    fr_t out = pair_permute<17>(s, P, true, 1);
     if (live && !s.isY) stg(h + i, out);
 }
 
 // K4 (pair form): one Merkle level / the pair-leaf level (DsJob as in poseidon_dev.hpp).
-__global__ void __launch_bounds__(128) k_hash_ds2(PoseidonDev P, DsJob J, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
+template <int T>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k_hash_ds2(PoseidonDev P, DsJob J, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
-    const int t = P.t, rate = t - 1;
-    PairState s = pair_setup(lds, t);
+    constexpr int rate = T - 1;
+    PairState s = pair_setup(lds);
     const size_t k0 = (size_t)blockIdx.x * 64 + s.lane; const bool live = k0 < J.n_out; const size_t k = live ? k0 : J.n_out - 1;
-    { const int j0 = s.isY ? s.nx : 0, j1 = s.isY ? t : s.nx; for (int j = j0; j < j1; ++j) s.sto(j, fr_zero<PF>()); }
+    const int o0 = s.isY ? PairCfg<T>::NX : 0, o1 = s.isY ? T : PairCfg<T>::NX;      // elements this wave fills / absorbs into
+    for (int j = o0; j < o1; ++j) s.sto(j, fr_zero<PF>());
     __syncthreads();
     const size_t cnt = J.mode == 1 ? 2 : ((k + 1) * J.arity <= J.n_in ? J.arity : J.n_in - k * J.arity);
     const size_t total = 4 + cnt + 1, nperm = (total + rate - 1) / rate;
@@ -168,7 +214,7 @@ __global__ void __launch_bounds__(128) k_hash_ds2(PoseidonDev P, DsJob J, const 
         const bool active = pidx < nperm;
         if (active) {
             for (int cur = 0; cur < rate && q < total; ++cur, ++q) {
-                if (!s.owns(cur)) continue;
+                if (cur < o0 || cur >= o1) continue;
                 fr_t x;
                 if (q == 0) x = J.arity_f; else if (q == 1) x = J.level_f; else if (q == 2) x = fr_from_u64<PF>(J.pos0 + k); else if (q == 3) x = J.label_f;
                 else if (q == total - 1) x = fr_one<PF>();
@@ -178,7 +224,7 @@ __global__ void __launch_bounds__(128) k_hash_ds2(PoseidonDev P, DsJob J, const 
         }
         __syncthreads();
         // lanes whose stream ended earlier keep their result and permute a dead state (values unused)
-        fr_t r2 = pair_permute(s, P, pidx + 1 == max_perm);
+        fr_t r2 = pair_permute<T>(s, P, pidx + 1 == max_perm);
         if (active && pidx + 1 == nperm) res = (pidx + 1 == max_perm) ? r2 : s.ld(0);
         __syncthreads();
     }

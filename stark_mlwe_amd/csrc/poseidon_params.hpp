@@ -12,6 +12,7 @@ struct PoseidonDev {           // device pointers to kernel-form constants (see 
     const fr_t* sparse;        // rp*(2t-1)
     const fr_t* mds;           // t*t  reference form
     const fr_t* mds_pre;       // t*t  dense B_1*M
+    const fr_t* gamma;         // (rp/4)*6  cross terms of the 4-round partial blocks
 };
 
 }  // namespace stark
