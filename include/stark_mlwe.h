@@ -45,6 +45,7 @@ typedef struct stark_params stark_params_t;
 typedef struct stark_tree stark_tree_t;
 typedef struct stark_fri_state stark_fri_state_t;
 typedef struct stark_proof stark_proof_t;
+typedef struct stark_fri_plan stark_fri_plan_t;
 
 /* ---- context / memory ------------------------------------------------------------------------- */
 int32_t stark_version(void);
@@ -163,6 +164,32 @@ int32_t stark_proof_bytes(stark_proof_t* p, uint8_t* out);
 size_t  stark_proof_size_estimate(stark_proof_t* p);                /* deep_fri_proof_size_bytes, fri.rs:764-805 */
 double  stark_proof_stage_ms(stark_proof_t* p, int32_t stage);     /* 0 build_f0, 1 fri_build, 2 queries+encode */
 int32_t stark_proof_free(stark_proof_t* p);
+
+/* ---- One trace sharded over several GPUs ------------------------------------------
+ * The commit phase shards by contiguous blocks (folds, leaf hashes and lower Merkle levels are
+ * block-local: stark_fri_fold_dev, stark_leaf_pair_hash_dev, stark_merkle_build_dev with first_pos /
+ * level0 / stop_at_len).  The pieces below complete the path without callbacks across the ABI:
+ *  - stark_ali_merge_shard_dev: deep_ali_merge_evals(_blinded) (deep_ali/src/lib.rs:48-105) on the local
+ *    block [j0, j0+n_local) of an n_global-point domain (omega4 NULL => the radix-2 domain generator); *partial4 (host, may be NULL) receives the
+ *    block's share of sum_j phi_j w^j/(z - w^j); stark_ali_cstar_from_partials combines the ranks' shares
+ *    (c* = (1/n) * sum, lib.rs:44,94).
+ *  - stark_ali_challenges: (seed, z, beta) of DeepAliRealBuilder::build_f0 from the four column digests
+ *    (fri.rs:551-560, ali_sample_z_beta_fs :511-533); digests16 = H(a),H(s),H(e),H(t) (host), aux12 = seed,z,beta (host).
+ *    The column digests themselves are stark_tr_hash_fields_tagged_dev(tag "ALI/A|S|E|T", k = n0, n_hashes = 1).
+ *  - query phase of deep_fri_prove (fri.rs:355-466, 613-640) over values that live on other ranks:
+ *    plan_create derives every query index from the L+1 roots and lists the values the proof needs
+ *    (kind 0: element `index` of layer `which`; kind 1: node `index` at `level` of tree `which`);
+ *    the caller collects them (each from its owner) and plan_assemble returns the canonical proof bytes. */
+int32_t stark_ali_merge_shard_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt,
+                                  const uint64_t* beta4, const uint64_t* omega4, const uint64_t* z4, size_t n_local, uint64_t j0, size_t n_global,
+                                  uint64_t* f0, uint64_t* partial4);
+int32_t stark_ali_cstar_from_partials(stark_ctx_t* ctx, const uint64_t* partials, size_t k, size_t n_global, uint64_t* c_star4);
+int32_t stark_ali_challenges(stark_ctx_t* ctx, const uint64_t* digests16, size_t n0, uint64_t* aux12);
+int32_t stark_fri_plan_create(stark_ctx_t* ctx, const uint64_t* roots, size_t n0, const size_t* schedule, size_t L, size_t r, stark_fri_plan_t** out);
+size_t  stark_fri_plan_num_requests(stark_fri_plan_t* p);
+int32_t stark_fri_plan_requests(stark_fri_plan_t* p, uint32_t* kind, uint32_t* which, uint32_t* level, uint64_t* index);
+int32_t stark_fri_plan_assemble(stark_fri_plan_t* p, const uint64_t* values, size_t n_values, stark_proof_t** out);
+int32_t stark_fri_plan_free(stark_fri_plan_t* p);
 
 /* ---- NTT (crates/fft/src/lib.rs:6-32) ------------------------------------------------------------- */
 /* fft_in_place / ifft_in_place: natural order in and out; inverse != 0 includes the n^-1 scaling.

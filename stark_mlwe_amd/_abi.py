@@ -85,6 +85,14 @@ SIGNATURES = {
     "stark_proof_size_estimate": (sz, [vp]),
     "stark_proof_stage_ms": (C.c_double, [vp, i32]),
     "stark_proof_free": (i32, [vp]),
+    "stark_ali_merge_shard_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, u64, sz, vp, vp]),
+    "stark_ali_cstar_from_partials": (i32, [vp, vp, sz, sz, vp]),
+    "stark_ali_challenges": (i32, [vp, vp, sz, vp]),
+    "stark_fri_plan_create": (i32, [vp, vp, sz, vp, sz, sz, vpp]),
+    "stark_fri_plan_num_requests": (sz, [vp]),
+    "stark_fri_plan_requests": (i32, [vp, vp, vp, vp, vp]),
+    "stark_fri_plan_assemble": (i32, [vp, vp, sz, vpp]),
+    "stark_fri_plan_free": (i32, [vp]),
     "stark_ntt": (i32, [vp, i32, vp, sz, i32, vp]),
     "stark_ntt_dev": (i32, [vp, i32, vp, sz, i32, vp]),
     "stark_lde": (i32, [vp, i32, vp, sz, sz, vp, vp]),

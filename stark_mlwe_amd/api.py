@@ -148,6 +148,31 @@ class FriProverState:
             self.h = None
 
 
+class FriQueryPlan:
+    """stark_fri_plan_t: the values the query phase needs, by (kind, which, level, index), and the assembler."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def requests(self):
+        n = self.ctx.lib.stark_fri_plan_num_requests(self.h)
+        kind = np.zeros(n, np.uint32); which = np.zeros(n, np.uint32); level = np.zeros(n, np.uint32); index = np.zeros(n, np.uint64)
+        if n:
+            self.ctx._chk(self.ctx.lib.stark_fri_plan_requests(self.h, _ptr(kind), _ptr(which), _ptr(level), _ptr(index)))
+        return kind, which, level, index
+
+    def assemble(self, values):
+        v = _arr(values).reshape(-1, 4)
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.lib.stark_fri_plan_assemble(self.h, _ptr(v), v.shape[0], C.byref(h)))
+        return self.ctx._proof_out(h)
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.stark_fri_plan_free(self.h)
+            self.h = None
+
+
 class DeepFriParams:
     """fri.rs:589."""
 
@@ -339,6 +364,32 @@ class Context:
         finally:
             self.lib.stark_proof_free(h)
         return bytes(buf), est, ms
+
+    def _proof_out(self, h):
+        try:
+            ln = self.lib.stark_proof_len(h)
+            buf = (C.c_uint8 * ln)()
+            self._chk(self.lib.stark_proof_bytes(h, buf))
+            est = self.lib.stark_proof_size_estimate(h)
+        finally:
+            self.lib.stark_proof_free(h)
+        return bytes(buf), est
+
+    # ---- one trace sharded over several GPUs: the pieces stark_mlwe_amd.dist composes ----------------------
+    def ali_challenges(self, digests, n0):
+        """(seed, z, beta) of DeepAliRealBuilder::build_f0 from the four column digests (fri.rs:551-560)."""
+        d = _arr(digests)
+        aux = np.zeros((3, 4), np.uint64)
+        self._chk(self.lib.stark_ali_challenges(self.h, _ptr(d), n0, _ptr(aux)))
+        return aux
+
+    def fri_query_plan(self, roots, n0, schedule, r):
+        """Query plan of deep_fri_prove over roots only (fri.rs:355-466): FriQueryPlan with .requests()."""
+        rt = _arr(roots)
+        sch = np.ascontiguousarray(schedule, dtype=np.uint64)
+        h = C.c_void_p()
+        self._chk(self.lib.stark_fri_plan_create(self.h, _ptr(rt), n0, _ptr(sch), len(sch), r, C.byref(h)))
+        return FriQueryPlan(self, h)
 
     # ---- fft (crates/fft/src/lib.rs:6-32) ------------------------------------------------------------
     def fft(self, coeffs, field=BLS12_381_FR, coset=None):

@@ -401,41 +401,22 @@ int32_t stark_merkle_free(stark_tree_t* t) { if (!t) return STARK_ERR_INVALID_AR
 
 }  // extern "C"
 
-// open_union_of_paths (merkle/src/lib.rs:246-315): host index logic + device gathers of the siblings.
+// open_union_of_paths (merkle/src/lib.rs:246-315): host index logic (fri_plan.hpp) + device gathers of the siblings.
 namespace stark {
+struct TreeSource : FriSource {
+    stark_tree* t; explicit TreeSource(stark_tree* t_) : t(t_) {}
+    int32_t layer(size_t, const std::vector<size_t>&, std::vector<fr_t>&) override { return STARK_ERR_INVALID_ARG; }
+    int32_t digests(size_t, size_t level, const std::vector<size_t>& idx, std::vector<fr_t>& out) override {
+        out.resize(idx.size()); return stark_merkle_gather(t, (int32_t)level, idx.data(), idx.size(), (uint64_t*)out.data());
+    }
+};
 int32_t merkle_open_host(stark_tree* t, const std::vector<size_t>& indices, MerkleProofHost& pr) {
     stark_ctx* ctx = t->ctx;
     if (indices.empty()) return ctx->fail(STARK_ERR_INVALID_ARG, "open_many: empty indices");                           // :247
     if (t->lens.back() != 1) return ctx->fail(STARK_ERR_INVALID_ARG, "cannot open a partial tree");
-    std::vector<size_t> cur = indices; std::sort(cur.begin(), cur.end()); cur.erase(std::unique(cur.begin(), cur.end()), cur.end());
-    if (cur.back() >= t->lens[0]) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf index out of range");
-    pr.arity = t->arity; pr.indices = cur;
-    const size_t arity = t->arity, height = t->levels.size() - 1;
-    for (size_t level = 0; level < height; ++level) {
-        const size_t len = t->lens[level];
-        std::vector<size_t> want; std::vector<uint8_t> gs;
-        size_t i = 0;
-        while (i < cur.size()) {                       // cur is sorted: one group per distinct parent
-            size_t parent = cur[i] / arity, base = parent * arity, end = std::min(base + arity, len);
-            gs.push_back((uint8_t)(end - base));
-            for (size_t c = base; c < end; ++c) { if (i < cur.size() && cur[i] == c) ++i; else want.push_back(c); }
-        }
-        std::vector<fr_t> sib(want.size());
-        if (!want.empty()) STARK_TRY(stark_merkle_gather(t, (int32_t)level, want.data(), want.size(), (uint64_t*)sib.data()));
-        pr.siblings.push_back(std::move(sib)); pr.group_sizes.push_back(std::move(gs));
-        std::vector<size_t> nx; for (size_t x : cur) { size_t q = x / arity; if (nx.empty() || nx.back() != q) nx.push_back(q); }
-        cur.swap(nx);
-    }
-    return STARK_OK;
-}
-void enc_u64(std::vector<uint8_t>& b, uint64_t x) { for (int j = 0; j < 8; ++j) b.push_back((uint8_t)(x >> (8 * j))); }
-void enc_fr(std::vector<uint8_t>& b, const fr_t& x) { uint8_t t[32]; host::h_to_bytes_le(x, t); b.insert(b.end(), t, t + 32); }
-void enc_idxs(std::vector<uint8_t>& b, const std::vector<size_t>& v) { enc_u64(b, v.size()); for (size_t x : v) enc_u64(b, x); }
-void enc_mproof(std::vector<uint8_t>& b, const MerkleProofHost& p) {
-    enc_idxs(b, p.indices);
-    enc_u64(b, p.siblings.size()); for (auto& l : p.siblings) { enc_u64(b, l.size()); for (auto& x : l) enc_fr(b, x); }
-    enc_u64(b, p.group_sizes.size()); for (auto& l : p.group_sizes) { enc_u64(b, l.size()); for (uint8_t x : l) b.push_back(x); }
-    enc_u64(b, p.arity);
+    for (size_t i : indices) if (i >= t->lens[0]) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf index out of range");
+    TreeSource src(t);
+    return merkle_open_from(src, 0, t->lens, t->arity, indices, pr);
 }
 }  // namespace stark
 

@@ -20,13 +20,7 @@ struct stark_fri_state {
 struct stark_proof { std::vector<uint8_t> bytes; size_t size_estimate = 0; double ms[3] = {0, 0, 0}; };
 
 static inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
-static inline int ilog2(size_t x) { int k = 0; while (((size_t)1 << k) < x) ++k; return k; }
-static inline size_t pick_arity_for_layer(size_t n, size_t m) {    // fri.rs:220-229
-    if (m >= 128 && n % 128 == 0) return 128; if (m >= 64 && n % 64 == 0) return 64; if (m >= 32 && n % 32 == 0) return 32;
-    if (m >= 16 && n % 16 == 0) return 16; if (m >= 8 && n % 8 == 0) return 8; if (m >= 4 && n % 4 == 0) return 4;
-    if (n % 2 == 0) return 2; return 1;
-}
-static inline bool hashed_arity(size_t a) { return a == 128 || a == 64 || a == 32 || a == 16 || a == 8; }   // fri.rs:275
+static inline int ilog2(size_t x) { return ilog2_ceil(x); }
 
 // z^0..z^(m-1) on the device (m <= a few hundred: host powers, one small upload).
 static int32_t upload_zpows(stark_ctx* ctx, const fr_t& z, size_t m, DevBuf& d) {
@@ -123,11 +117,14 @@ static int32_t fri_build_impl(stark_ctx* ctx, const fr_t* f0_dev, size_t n0, con
 
 // deep_ali_merge_evals_blinded on device pointers (deep_ali/src/lib.rs:60-105).
 static int32_t ali_merge_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, const fr_t* e, const fr_t* t, const fr_t* r_opt, const fr_t& beta,
-                                  const fr_t& omega, const fr_t& z, size_t n, fr_t* f0, fr_t* c_star_host) {
-    if (n <= 1) return ctx->fail(STARK_ERR_INVALID_ARG, "n > 1");                                                          // lib.rs:71
-    if (fr_eq(fr_pow_u64<PallasFr>(z, n), host::h_one())) return ctx->fail(STARK_ERR_INVALID_ARG, "z must be outside H");   // lib.rs:78
-    // power table of omega: two levels of 2^ceil(b/2) entries, b = bits of n
-    int bits = ilog2(n); if (bits < 1) bits = 1; int lo_bits = (bits + 1) / 2, hi_bits = bits - lo_bits + 1;
+                                  const fr_t& omega, const fr_t& z, size_t n, fr_t* f0, fr_t* c_star_host,
+                                  uint64_t j0 = 0, size_t n_global = 0, bool partial_only = false) {
+    // n = number of local elements, holding the global positions j0 .. j0+n-1 of a domain of n_global points (whole vector: j0 = 0, n_global = n)
+    if (!n_global) n_global = n;
+    if (n_global <= 1 || !n || j0 + n > n_global) return ctx->fail(STARK_ERR_INVALID_ARG, "n > 1");                        // lib.rs:71
+    if (fr_eq(fr_pow_u64<PallasFr>(z, n_global), host::h_one())) return ctx->fail(STARK_ERR_INVALID_ARG, "z must be outside H");   // lib.rs:78
+    // power table of omega: two levels of 2^ceil(b/2) entries, b = bits of n_global
+    int bits = ilog2(n_global); if (bits < 1) bits = 1; int lo_bits = (bits + 1) / 2, hi_bits = bits - lo_bits + 1;
     DevBuf tlo, thi; STARK_HIP(ctx, tlo.alloc(((size_t)1 << lo_bits) * sizeof(fr_t))); STARK_HIP(ctx, thi.alloc(((size_t)1 << hi_bits) * sizeof(fr_t)));
     { uint64_t tot = (1ull << lo_bits) + (1ull << hi_bits);
       hipLaunchKernelGGL(k_fill_pow_table<PallasFr>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tlo.fr(), thi.fr(), lo_bits, hi_bits, omega, host::h_one());
@@ -137,12 +134,12 @@ static int32_t ali_merge_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, 
     const uint64_t T = (uint64_t)grid * block;
     fr_t w_step = fr_pow_u64<PallasFr>(omega, T);
     DevBuf sums; STARK_HIP(ctx, sums.alloc((size_t)grid * sizeof(fr_t)));
-    hipLaunchKernelGGL(k_ali_merge<PallasFr>, dim3(grid), dim3(block), 0, ctx->stream, a, s, e, t, r_opt, beta, wp, w_step, fr_inv<PallasFr>(w_step), z, (uint64_t)n, f0, c_star_host ? sums.fr() : (fr_t*)nullptr);
+    hipLaunchKernelGGL(k_ali_merge<PallasFr>, dim3(grid), dim3(block), 0, ctx->stream, a, s, e, t, r_opt, beta, wp, w_step, fr_inv<PallasFr>(w_step), z, (uint64_t)n, j0, f0, c_star_host ? sums.fr() : (fr_t*)nullptr);
     STARK_HIP(ctx, hipGetLastError());
     if (c_star_host) {
         // c* = phi(z)/Z_H(z) = (1/n) * sum_j phi_j w^j/(z - w^j)   (lib.rs:44 and :94); block partials are reduced on the device
         DevBuf tot; STARK_HIP(ctx, tot.alloc(sizeof(fr_t)));
-        hipLaunchKernelGGL(k_sum_single_block<PallasFr>, dim3(1), dim3(256), 0, ctx->stream, (const fr_t*)sums.fr(), (uint64_t)grid, fr_inv<PallasFr>(host::h_u64(n)), tot.fr());
+        hipLaunchKernelGGL(k_sum_single_block<PallasFr>, dim3(1), dim3(256), 0, ctx->stream, (const fr_t*)sums.fr(), (uint64_t)grid, partial_only ? host::h_one() : fr_inv<PallasFr>(host::h_u64(n_global)), tot.fr());
         STARK_HIP(ctx, hipGetLastError());
         STARK_HIP(ctx, hipMemcpyAsync(c_star_host, tot.p, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -182,73 +179,50 @@ static int32_t build_f0_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, c
 }
 
 // fri_prove_queries + payload assembly + canonical encoding (fri.rs:355-466, 613-640).
-static int32_t prove_queries_encode(stark_ctx* ctx, stark_fri_state* S, size_t n0, size_t r, stark_proof* P) {
-    const size_t L = S->schedule.size();
-    fr_t roots_seed; STARK_TRY(tr_hash_host1(ctx, "FRI/seed", S->roots, &roots_seed));                       // fs_seed_from_roots, fri.rs:178
-    // index seeds for all (q, l) in one batch of transcript hashes (fri.rs:374, :189-191)
-    std::vector<fr_t> in(3 * r * L); for (size_t q = 0; q < r; ++q) for (size_t l = 0; l < L; ++l) { fr_t* p = &in[3 * (q * L + l)]; p[0] = roots_seed; p[1] = host::h_u64(l); p[2] = host::h_u64(q); }
-    std::vector<fr_t> seeds(r * L);
-    if (r * L) STARK_TRY(stark_tr_hash_fields_tagged(ctx, nullptr, "FRI/index", (const uint64_t*)in.data(), 3, r * L, (uint64_t*)seeds.data()));
-    auto index_from_seed = [](const fr_t& sd, size_t n_pow2) { uint8_t b[32]; host::h_to_bytes_le(sd, b); host::ChaCha12Rng rng(b); return (size_t)rng.next_u64() & (n_pow2 - 1); };   // fri.rs:180-187
-    struct Ref { size_t i, child_pos, parent_index, parent_pos; };
-    std::vector<std::vector<Ref>> refs(r, std::vector<Ref>(L));
-    std::vector<std::vector<size_t>> child_b(L), parent_b(L);
-    for (size_t q = 0; q < r; ++q) for (size_t l = 0; l < L; ++l) {
-        size_t n = S->n[l], n_pow2 = 1; while (n_pow2 < n) n_pow2 <<= 1; size_t m = S->schedule[l];
-        const fr_t& seed = seeds[q * L + l];
-        size_t i0 = index_from_seed(seed, n_pow2), i;
-        if (i0 < n) i = i0;
-        else { fr_t reseed; STARK_TRY(tr_hash_host1(ctx, "FRI/index", {seed, host::h_u64(1)}, &reseed)); size_t i2 = index_from_seed(reseed, n_pow2); i = i2 < n ? i2 : (i2 & (n - 1)); }   // fri.rs:379-381
-        refs[q][l] = Ref{i, 0, i / m, 0}; child_b[l].push_back(i); parent_b[l].push_back(i / m);
-    }
-    std::vector<uint8_t>& b = P->bytes; b.clear();
-    size_t est = S->roots.size() * 32 + 32 + 8;                                                               // fri.rs:779-783
-    enc_u64(b, S->roots.size()); for (auto& x : S->roots) enc_fr(b, x);
-    enc_u64(b, L);
-    std::vector<std::vector<size_t>> ci(L), pi(L);
-    for (size_t l = 0; l < L; ++l) {
-        ci[l] = child_b[l]; std::sort(ci[l].begin(), ci[l].end()); ci[l].erase(std::unique(ci[l].begin(), ci[l].end()), ci[l].end());
-        pi[l] = parent_b[l]; std::sort(pi[l].begin(), pi[l].end()); pi[l].erase(std::unique(pi[l].begin(), pi[l].end()), pi[l].end());
-        MerkleProofHost cp, pp; STARK_TRY(merkle_open_host(S->trees[l], ci[l], cp)); STARK_TRY(merkle_open_host(S->trees[l + 1], pi[l], pp));
-        b.push_back(S->hashed[l] ? 1 : 0); enc_idxs(b, ci[l]); enc_mproof(b, cp); enc_idxs(b, pi[l]); enc_mproof(b, pp);
-        for (auto& g : cp.siblings) est += g.size() * 32; for (auto& g : pp.siblings) est += g.size() * 32;
-        est += ci[l].size() * 8 + pi[l].size() * 8;
-        for (size_t q = 0; q < r; ++q) {
-            refs[q][l].child_pos = (size_t)(std::lower_bound(ci[l].begin(), ci[l].end(), refs[q][l].i) - ci[l].begin());
-            refs[q][l].parent_pos = (size_t)(std::lower_bound(pi[l].begin(), pi[l].end(), refs[q][l].parent_index) - pi[l].begin());
-        }
-    }
-    { MerkleProofHost fp; STARK_TRY(merkle_open_host(S->trees[L], std::vector<size_t>{0}, fp)); enc_mproof(b, fp); for (auto& g : fp.siblings) est += g.size() * 32; }
-    // opened field elements: f_i, s_i = f_{l+1}[i/m], f_parent_b = f_{l+1}[b], s_parent_b = f_{l+2}[b/m_{l+1}] (0 on the last layer)
-    std::vector<std::vector<fr_t>> fi(L), fpar(L), spar(L);
-    auto gather_layer = [&](size_t layer, const std::vector<size_t>& idx, std::vector<fr_t>& outv) -> int32_t {
+// Sources of the query phase (fri_plan.hpp): the device-resident state of one GPU, and the device transcript hasher.
+struct LocalSource : FriSource {
+    stark_ctx* ctx; stark_fri_state* S;
+    LocalSource(stark_ctx* c, stark_fri_state* s) : ctx(c), S(s) {}
+    int32_t layer(size_t l, const std::vector<size_t>& idx, std::vector<fr_t>& outv) override {
         outv.resize(idx.size()); if (idx.empty()) return STARK_OK;
+        if (l >= S->f.size()) return ctx->fail(STARK_ERR_INVALID_ARG, "layer out of range");
+        for (size_t i : idx) if (i >= S->n[l]) return ctx->fail(STARK_ERR_INVALID_ARG, "layer index out of range");
         DevBuf di, dout; STARK_HIP(ctx, di.alloc(idx.size() * 8)); STARK_HIP(ctx, dout.alloc(idx.size() * sizeof(fr_t)));
         std::vector<uint64_t> ix(idx.begin(), idx.end());
         STARK_HIP(ctx, hipMemcpyAsync(di.p, ix.data(), ix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gather, dim3((unsigned)((ix.size() + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t*)S->f[layer], (const uint64_t*)di.p, (uint64_t)ix.size(), dout.fr());
+        hipLaunchKernelGGL(k_gather, dim3((unsigned)((ix.size() + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t*)S->f[l], (const uint64_t*)di.p, (uint64_t)ix.size(), dout.fr());
         STARK_HIP(ctx, hipGetLastError());
         STARK_HIP(ctx, hipMemcpyAsync(outv.data(), dout.p, ix.size() * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return STARK_OK;
-    };
-    for (size_t l = 0; l < L; ++l) {
-        std::vector<size_t> a(r), bb(r), cc(r);
-        for (size_t q = 0; q < r; ++q) { a[q] = refs[q][l].i; bb[q] = refs[q][l].parent_index; cc[q] = l + 1 < L ? refs[q][l].parent_index / S->schedule[l + 1] : 0; }
-        STARK_TRY(gather_layer(l, a, fi[l])); STARK_TRY(gather_layer(l + 1, bb, fpar[l]));
-        if (l + 1 < L) STARK_TRY(gather_layer(l + 2, cc, spar[l])); else spar[l].assign(r, host::h_zero());
     }
-    std::vector<fr_t> last_f; STARK_TRY(gather_layer(L, std::vector<size_t>{0}, last_f));
-    enc_u64(b, r);
-    for (size_t q = 0; q < r; ++q) {
-        enc_u64(b, L); for (size_t l = 0; l < L; ++l) { enc_u64(b, refs[q][l].i); enc_u64(b, refs[q][l].child_pos); enc_u64(b, refs[q][l].parent_index); enc_u64(b, refs[q][l].parent_pos); }
-        enc_u64(b, L); for (size_t l = 0; l < L; ++l) { enc_fr(b, fi[l][q]); enc_fr(b, fpar[l][q]) /* s_i == f_parent_b */; enc_fr(b, fpar[l][q]); enc_fr(b, spar[l][q]); }
-        enc_u64(b, 0); enc_fr(b, last_f[0]); enc_fr(b, host::h_zero());                                        // final_index, final_pair (fri.rs:398-399; last s is zero, :266)
-        est += 8 + 2 * 32 + L * 16 + L * 128;                                                                 // fri.rs:796-801
+    int32_t digests(size_t tree, size_t level, const std::vector<size_t>& idx, std::vector<fr_t>& out) override {
+        if (tree >= S->trees.size()) return ctx->fail(STARK_ERR_INVALID_ARG, "tree out of range");
+        out.resize(idx.size()); return stark_merkle_gather(S->trees[tree], (int32_t)level, idx.data(), idx.size(), (uint64_t*)out.data());
     }
-    enc_u64(b, n0); enc_fr(b, fr_root_of_unity<PallasFr>((unsigned)ilog2(n0)));
-    P->size_estimate = est;
+};
+struct DeviceHasher : TrHasher {
+    stark_ctx* ctx; explicit DeviceHasher(stark_ctx* c) : ctx(c) {}
+    int32_t hash(const char* tag, const fr_t* fields, size_t k, size_t n, fr_t* out) override {
+        if (n == 1) return tr_hash_host1(ctx, tag, std::vector<fr_t>(fields, fields + k), out);
+        return stark_tr_hash_fields_tagged(ctx, nullptr, tag, (const uint64_t*)fields, k, n, (uint64_t*)out);
+    }
+};
+static int32_t shape_of_state(stark_ctx* ctx, stark_fri_state* S, size_t n0, FriShape& sh) {
+    std::string err;
+    if (!sh.make(n0, S->schedule.data(), S->schedule.size(), S->roots.data(), err)) return ctx->fail(STARK_ERR_INVALID_ARG, err);
     return STARK_OK;
 }
+// fri_prove_queries + payload assembly + canonical encoding (fri.rs:355-466, 613-640): fri_plan.hpp over the local state.
+static int32_t prove_queries_encode(stark_ctx* ctx, stark_fri_state* S, size_t n0, size_t r, stark_proof* P) {
+    FriShape sh; STARK_TRY(shape_of_state(ctx, S, n0, sh));
+    LocalSource src(ctx, S); DeviceHasher H(ctx);
+    int32_t rc = assemble_proof(sh, r, H, src, P->bytes, P->size_estimate);
+    if (rc == -1) return ctx->fail(STARK_ERR_INVALID_ARG, "query phase: bad index or short value list");
+    return rc;
+}
+
+// Query plan of a commit phase whose layers live elsewhere (sharded over ranks): see fri_plan.hpp.
+struct stark_fri_plan { stark_ctx* ctx = nullptr; FriPlan plan; };
 
 static int32_t prove_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, const fr_t* e, const fr_t* t, const fr_t* f0_in, size_t n0,
                           const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof** out) {
@@ -355,5 +329,54 @@ int32_t stark_proof_bytes(stark_proof_t* p, uint8_t* out) { if (!p || !out) retu
 size_t stark_proof_size_estimate(stark_proof_t* p) { return p ? p->size_estimate : 0; }
 double stark_proof_stage_ms(stark_proof_t* p, int32_t stage) { return (p && stage >= 0 && stage < 3) ? p->ms[stage] : -1.0; }
 int32_t stark_proof_free(stark_proof_t* p) { if (!p) return STARK_ERR_INVALID_ARG; delete p; return STARK_OK; }
+
+// ---- one trace sharded over several GPUs: the pieces the orchestrator (stark_mlwe_amd/dist.py) composes --------
+int32_t stark_ali_merge_shard_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt, const uint64_t* beta4,
+                                  const uint64_t* omega4, const uint64_t* z4, size_t n_local, uint64_t j0, size_t n_global, uint64_t* f0, uint64_t* partial4) {
+    if (!ctx || !a || !s || !e || !t || !z4 || !f0 || (r_opt && !beta4) || !n_global) return STARK_ERR_INVALID_ARG;
+    const fr_t omega = omega4 ? load_fr(omega4) : fr_root_of_unity<PallasFr>((unsigned)ilog2(n_global));               // FriDomain::new_radix2(n).omega, fri.rs:53-56
+    fr_t ps; STARK_TRY(ali_merge_dev_impl(ctx, as_fr(a), as_fr(s), as_fr(e), as_fr(t), as_fr(r_opt), beta4 ? load_fr(beta4) : host::h_zero(), omega, load_fr(z4), n_local, as_fr(f0),
+                                          partial4 ? &ps : nullptr, j0, n_global, true));
+    if (partial4) store_fr(partial4, ps); return STARK_OK;
+}
+int32_t stark_ali_cstar_from_partials(stark_ctx_t* ctx, const uint64_t* partials, size_t k, size_t n_global, uint64_t* c_star4) {
+    if (!ctx || (!partials && k) || !c_star4 || !n_global) return STARK_ERR_INVALID_ARG;
+    fr_t acc = host::h_zero(); for (size_t i = 0; i < k; ++i) acc = host::h_add(acc, load_fr(partials + 4 * i));
+    store_fr(c_star4, fr_mul<PallasFr>(acc, fr_inv<PallasFr>(host::h_u64(n_global)))); return STARK_OK;                  // c* = (1/n) * sum (lib.rs:44, :94)
+}
+int32_t stark_ali_challenges(stark_ctx_t* ctx, const uint64_t* digests16, size_t n0, uint64_t* aux12) {
+    if (!ctx || !digests16 || !aux12 || n0 <= 1) return STARK_ERR_INVALID_ARG;
+    fr_t h[5]; for (int c = 0; c < 4; ++c) h[c] = load_fr(digests16 + 4 * c); h[4] = host::h_u64(n0);
+    fr_t seed_f; STARK_TRY(tr_hash_host1(ctx, "ALI/seed", std::vector<fr_t>(h, h + 5), &seed_f));                       // fri.rs:556-557
+    fr_t z, beta; STARK_TRY(ali_sample_z_beta(ctx, "ALI/DEEP", n0, seed_f, &z, &beta));
+    store_fr(aux12, seed_f); store_fr(aux12 + 4, z); store_fr(aux12 + 8, beta); return STARK_OK;
+}
+int32_t stark_fri_plan_create(stark_ctx_t* ctx, const uint64_t* roots, size_t n0, const size_t* schedule, size_t L, size_t r, stark_fri_plan_t** out) {
+    if (!ctx || !roots || !out || (!schedule && L)) return STARK_ERR_INVALID_ARG;
+    std::vector<fr_t> rt(L + 1); for (size_t l = 0; l <= L; ++l) rt[l] = load_fr(roots + 4 * l);
+    stark_fri_plan* P = new stark_fri_plan(); P->ctx = ctx; P->plan.r = r;
+    std::string err; if (!P->plan.shape.make(n0, schedule, L, rt.data(), err)) { delete P; return ctx->fail(STARK_ERR_INVALID_ARG, err); }
+    DeviceHasher H(ctx); int32_t rc = fri_plan_make(P->plan, H);
+    if (rc) { delete P; return rc == -1 ? ctx->fail(STARK_ERR_INVALID_ARG, "query plan") : rc; }
+    *out = P; return STARK_OK;
+}
+size_t stark_fri_plan_num_requests(stark_fri_plan_t* p) { return p ? p->plan.req.size() : 0; }
+int32_t stark_fri_plan_requests(stark_fri_plan_t* p, uint32_t* kind, uint32_t* which, uint32_t* level, uint64_t* index) {
+    if (!p || !kind || !which || !level || !index) return STARK_ERR_INVALID_ARG;
+    for (size_t i = 0; i < p->plan.req.size(); ++i) { kind[i] = p->plan.req[i].kind; which[i] = p->plan.req[i].which; level[i] = p->plan.req[i].level; index[i] = p->plan.req[i].index; }
+    return STARK_OK;
+}
+int32_t stark_fri_plan_assemble(stark_fri_plan_t* p, const uint64_t* values, size_t n_values, stark_proof_t** out) {
+    if (!p || (!values && n_values) || !out) return STARK_ERR_INVALID_ARG;
+    stark_ctx* ctx = p->ctx;
+    if (n_values != p->plan.req.size()) return ctx->fail(STARK_ERR_INVALID_ARG, "value count differs from the plan's request count");
+    std::vector<fr_t> v(n_values); for (size_t i = 0; i < n_values; ++i) v[i] = load_fr(values + 4 * i);
+    ReplaySource src(v.data(), v.size()); DeviceHasher H(ctx);
+    stark_proof* P = new stark_proof();
+    int32_t rc = assemble_proof(p->plan.shape, p->plan.r, H, src, P->bytes, P->size_estimate);
+    if (rc || src.pos != v.size()) { delete P; return ctx->fail(STARK_ERR_INVALID_ARG, "assemble: values do not match the plan"); }
+    *out = P; return STARK_OK;
+}
+int32_t stark_fri_plan_free(stark_fri_plan_t* p) { if (!p) return STARK_ERR_INVALID_ARG; delete p; return STARK_OK; }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 #include "host_util.hpp"
 #include "poseidon_params.hpp"
 #include "ntt_dev.hpp"
+#include "fri_plan.hpp"
 
 namespace stark {
 
@@ -77,13 +78,8 @@ struct DevBuf {
     void* release() { void* q = p; p = nullptr; return q; }
 };
 
-// MerkleProof (merkle/src/lib.rs:131-143) on the host side of the product + canonical encoders.
-struct MerkleProofHost { std::vector<size_t> indices; std::vector<std::vector<fr_t>> siblings; std::vector<std::vector<uint8_t>> group_sizes; size_t arity = 0; };
+// open_union_of_paths over a device-resident tree (MerkleProofHost and the encoders: fri_plan.hpp)
 int32_t merkle_open_host(stark_tree* t, const std::vector<size_t>& indices, MerkleProofHost& pr);
-void enc_u64(std::vector<uint8_t>& b, uint64_t x);
-void enc_fr(std::vector<uint8_t>& b, const fr_t& x);
-void enc_idxs(std::vector<uint8_t>& b, const std::vector<size_t>& v);
-void enc_mproof(std::vector<uint8_t>& b, const MerkleProofHost& p);
 
 // shared internal entry points (defined in capi_core.hip / capi_fri.hip / capi_ntt.hip)
 int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out);

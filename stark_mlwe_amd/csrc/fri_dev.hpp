@@ -51,12 +51,12 @@ __global__ void __launch_bounds__(256) k_fri_fold_any(const fr_t* __restrict__ f
 #define ALI_K 8
 template <class F>
 __global__ void __launch_bounds__(256) k_ali_merge(const fr_t* __restrict__ a, const fr_t* __restrict__ s, const fr_t* __restrict__ e, const fr_t* __restrict__ t,
-                                                   const fr_t* __restrict__ r_opt, fr_t beta, PowTable wpow, fr_t w_step /* w^T */, fr_t w_step_inv, fr_t z, uint64_t n,
+                                                   const fr_t* __restrict__ r_opt, fr_t beta, PowTable wpow, fr_t w_step /* w^T */, fr_t w_step_inv, fr_t z, uint64_t n, uint64_t j0 /* global position of element 0 */,
                                                    fr_t* __restrict__ f0, fr_t* __restrict__ block_sums) {
     __shared__ uint4 red[2 * 4];
     const uint64_t T = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     fr_t phi[ALI_K], pre[ALI_K];
-    fr_t w = tid < n ? pow_lookup<F>(wpow, tid) : fr_one<F>();     // w^tid
+    fr_t w = tid < n ? pow_lookup<F>(wpow, j0 + tid) : fr_one<F>();     // w^(j0 + tid)
     fr_t run = fr_one<F>();
 #pragma unroll
     for (int u = 0; u < ALI_K; ++u) {                              // forward: phi_j and prefix products of (w^j - z)

@@ -10,6 +10,7 @@
 #include "fr.hpp"
 #include "host_util.hpp"
 #include "poseidon_dev.hpp"
+#include "fri_plan.hpp"
 
 using namespace stark;
 
@@ -117,5 +118,42 @@ int hc_hash_stream(void* params, int mode, const uint64_t* a, size_t na, const u
     for (size_t k = 0; k < n; ++k) { ArrayState s{st.data()}; st4(out + 4 * k, hash_stream_body(s, P->dev, mode, av.data(), na, bv.data(), nb, tag ? ld4(tag) : host::h_zero(), k)); }
     return 0;
 }
+
+// ---- query plan / assemble (fri_plan.hpp) with the transcript hashes computed on the host -------------------
+struct HcHasher : TrHasher {
+    void* tp; explicit HcHasher(void* p) : tp(p) {}
+    int32_t hash(const char* tag, const fr_t* fields, size_t k, size_t n, fr_t* out) override {
+        std::vector<uint64_t> in(4 * k * n), o(4 * n);
+        for (size_t i = 0; i < k * n; ++i) st4(in.data() + 4 * i, fields[i]);
+        int rc = hc_tr_hash(tp, tag, in.data(), k, n, o.data()); if (rc) return rc;
+        for (size_t i = 0; i < n; ++i) out[i] = ld4(o.data() + 4 * i);
+        return 0;
+    }
+};
+struct HcPlan { FriPlan plan; void* tp; };
+void* hc_fri_plan_create(void* tparams, const uint64_t* roots, size_t n0, const size_t* schedule, size_t L, size_t r) {
+    std::vector<fr_t> rt(L + 1); for (size_t l = 0; l <= L; ++l) rt[l] = ld4(roots + 4 * l);
+    HcPlan* P = new HcPlan(); P->tp = tparams; P->plan.r = r; std::string err;
+    if (!P->plan.shape.make(n0, schedule, L, rt.data(), err)) { delete P; return nullptr; }
+    HcHasher H(tparams); if (fri_plan_make(P->plan, H)) { delete P; return nullptr; }
+    return P;
+}
+size_t hc_fri_plan_num_requests(void* p) { return ((HcPlan*)p)->plan.req.size(); }
+int hc_fri_plan_requests(void* p, uint32_t* kind, uint32_t* which, uint32_t* level, uint64_t* index) {
+    auto& rq = ((HcPlan*)p)->plan.req;
+    for (size_t i = 0; i < rq.size(); ++i) { kind[i] = rq[i].kind; which[i] = rq[i].which; level[i] = rq[i].level; index[i] = rq[i].index; }
+    return 0;
+}
+// returns the encoded length (0 on error); writes at most cap bytes
+size_t hc_fri_plan_assemble(void* p, const uint64_t* values, size_t n_values, uint8_t* buf, size_t cap, size_t* est) {
+    HcPlan* P = (HcPlan*)p; if (n_values != P->plan.req.size()) return 0;
+    std::vector<fr_t> v(n_values); for (size_t i = 0; i < n_values; ++i) v[i] = ld4(values + 4 * i);
+    ReplaySource src(v.data(), v.size()); HcHasher H(P->tp); std::vector<uint8_t> b; size_t e = 0;
+    if (assemble_proof(P->plan.shape, P->plan.r, H, src, b, e) || src.pos != v.size()) return 0;
+    if (est) *est = e;
+    if (buf && cap >= b.size()) memcpy(buf, b.data(), b.size());
+    return b.size();
+}
+void hc_fri_plan_free(void* p) { delete (HcPlan*)p; }
 
 }  // extern "C"

@@ -1,10 +1,14 @@
 """Multi-GPU orchestration of the path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
 over xGMI on the GPU box, "gloo" in the CPU tests) for the exchanges, the C-ABI for all local compute.
 
-Only two steps of the path exchange data:
+Only these steps of the path exchange data:
 
 * the six-step NTT — ONE all-to-all (the row/column transpose between its two local phases);
-* the top of a sharded Merkle tree — an all-gather of a few digests.
+* the top of a sharded Merkle tree — an all-gather of a few digests;
+* `DistProver` (one trace block-sharded over the ranks, one proof): the column sponges of build_f0 need
+  whole columns (gather of column c to rank c mod W — the four chains then run task-parallel), a layer that
+  has become too small to shard is all-gathered once, and the query phase collects the few thousand opened
+  values from their owners with one all-reduce of a zero-filled table.
 
 Everything else (folds, leaf hashes, lower Merkle levels, the DEEP-ALI merge) is block-local with global
 indices.  The local compute is behind a small provider interface so that the same orchestration runs in
@@ -100,6 +104,74 @@ class HipProvider:
     def sync(self):
         self.ctx.sync()
 
+    # ---- the block-local steps of one sharded proof (DistProver) ------------------------------------------
+    def params_for_arity(self, arity):
+        return self.ctx.poseidon_params_for_arity(arity)
+
+    def new(self, n):
+        return torch.empty((n, 4), dtype=torch.int64, device=self.device)
+
+    def zeros(self, n):
+        return torch.zeros((n, 4), dtype=torch.int64, device=self.device)
+
+    def fri_sample_z(self, seed_z, level, n):
+        return self.ctx.fri_sample_z_ell(seed_z, level, n)
+
+    def fold(self, f, z, m):
+        n = f.shape[0]
+        out = self.new(n // m)
+        self.ctx._chk(self.lib.stark_fri_fold_dev(self.ctx.h, self._p(f), n, _npp(z), m, self._p(out)))
+        return out
+
+    def leaf_pair_hash(self, f, f_next, m):
+        out = self.new(f.shape[0])
+        self.ctx._chk(self.lib.stark_leaf_pair_hash_dev(self.ctx.h, self.ctx.transcript_params().h, self._p(f), None if f_next is None else self._p(f_next), f.shape[0], m, self._p(out)))
+        return out
+
+    def merkle_build_pairs(self, params, arity, tree_label, f, cp, n):
+        h = C.c_void_p()
+        self.ctx._chk(self.lib.stark_merkle_build_dev(self.ctx.h, params.h, arity, tree_label, self._p(f), n, 1, self._p(cp), 0, 0, 0, C.byref(h)))
+        return h
+
+    def merkle_num_levels(self, h):
+        return self.lib.stark_merkle_num_levels(h)
+
+    def merkle_level_len(self, h, lvl):
+        return self.lib.stark_merkle_level_len(h, lvl)
+
+    def merkle_gather(self, h, lvl, idx):
+        """numpy (k, 4) uint64: nodes idx[] of level lvl (a few digests: host hop)."""
+        import numpy as np
+        ix = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros((len(ix), 4), np.uint64)
+        self.ctx._chk(self.lib.stark_merkle_gather(h, lvl, ix.ctypes.data_as(C.c_void_p), len(ix), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def column_digest(self, tag: bytes, col):
+        """tr_hash_fields_tagged(tag, column) — the serial sponge of build_f0 (fri.rs:551-554); numpy (4,)."""
+        out = self.new(1)
+        self.ctx._chk(self.lib.stark_tr_hash_fields_tagged_dev(self.ctx.h, None, tag, self._p(col), col.shape[0], 1, self._p(out)))
+        self.ctx.sync()
+        return out.cpu().numpy().view("uint64")[0]
+
+    def ali_challenges(self, digests, n0):
+        return self.ctx.ali_challenges(digests, n0)
+
+    def ali_merge_shard(self, a, s, e, t, z, j0, n_global):
+        f0 = self.new(a.shape[0])
+        self.ctx._chk(self.lib.stark_ali_merge_shard_dev(self.ctx.h, self._p(a), self._p(s), self._p(e), self._p(t), None, None, None, _npp(z), a.shape[0], j0, n_global, self._p(f0), None))
+        return f0
+
+    def query_plan(self, roots, n0, schedule, r):
+        return self.ctx.fri_query_plan(roots, n0, schedule, r)
+
+
+def _npp(a):
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    _npp.keep = a                      # keep the buffer alive across the call that follows
+    return a.ctypes.data_as(C.c_void_p)
+
 
 class DistNtt:
     """Six-step NTT of size 2^log_n over the ranks of the default process group."""
@@ -178,3 +250,225 @@ def merkle_sharded_root(provider, params, arity, tree_label, leaves, n_local: in
     provider.merkle_free(ht)
     provider.merkle_free(h)
     return root[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# One trace, block-sharded over the ranks, one proof (deep_fri_prove, fri.rs:601-641).
+# ---------------------------------------------------------------------------------------------------------
+def pick_arity_for_layer(n, m):
+    """fri.rs:220-229 (index logic only)."""
+    for a in (128, 64, 32, 16, 8, 4):
+        if m >= a and n % a == 0:
+            return a
+    return 2 if n % 2 == 0 else 1
+
+
+def hashed_arity(a):
+    """fri.rs:275."""
+    return a in (128, 64, 32, 16, 8)
+
+
+def _allreduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """Sum of int64 tables in which every row is non-zero on exactly one rank (so the sum is a selection)."""
+    rank, W = world()
+    if W == 1:
+        return t
+    if dist.get_backend() == "nccl":
+        d = t.cuda(); dist.all_reduce(d); return d.cpu()
+    h = t.cpu().contiguous(); dist.all_reduce(h); return h
+
+
+def _gather_to(x: torch.Tensor, dst: int):
+    """Concatenation of every rank's block on rank dst (None elsewhere)."""
+    rank, W = world()
+    if W == 1:
+        return x
+    if dist.get_backend() != "nccl" and x.is_cuda:
+        hx = x.cpu(); parts = [torch.empty_like(hx) for _ in range(W)] if rank == dst else None
+        dist.gather(hx, parts, dst=dst)
+        return torch.cat(parts, dim=0).to(x.device) if rank == dst else None
+    parts = [torch.empty_like(x) for _ in range(W)] if rank == dst else None
+    dist.gather(x.contiguous(), parts, dst=dst)
+    return torch.cat(parts, dim=0) if rank == dst else None
+
+
+class _Layer:
+    """f_l and its commitment: either a contiguous block per rank (sharded) or a full copy on every rank."""
+    __slots__ = ("n", "sharded", "f", "arity", "hashed", "tree", "top", "nlev_local", "local_lens")
+
+
+class DistProver:
+    """deep_fri_prove over W ranks, rank q holding rows [q*n0/W, (q+1)*n0/W) of a, s, e, t.  Every rank returns
+    the same canonical proof bytes as a single-GPU (or the reference's) prove of the whole trace."""
+
+    COLUMN_TAGS = (b"ALI/A", b"ALI/S", b"ALI/E", b"ALI/T")          # fri.rs:551-554
+
+    def __init__(self, provider, n0, schedule, r, seed_z):
+        self.p, self.n0, self.schedule, self.r, self.seed_z = provider, n0, list(schedule), r, seed_z
+        self.rank, self.W = world()
+        if n0 % self.W:
+            raise ValueError("n0 must divide over the ranks")
+        n = n0
+        for m in self.schedule:                                       # fri.rs:150
+            if m < 2 or n % m:
+                raise ValueError("schedule not dividing domain size")
+            n //= m
+        self.layers = []
+        self.timings = {}
+
+    # -- build_f0 (DeepAliRealBuilder, fri.rs:535-569) -----------------------------------------------------
+    def build_f0(self, a, s, e, t):
+        import numpy as np
+        rank, W, n0 = self.rank, self.W, self.n0
+        nl = n0 // W
+        digests = torch.zeros((4, 4), dtype=torch.int64)
+        for c, col in enumerate((a, s, e, t)):                        # the four chains are independent: column c on rank c mod W
+            whole = _gather_to(col, c % W)
+            if rank == c % W:
+                digests[c] = torch.from_numpy(self.p.column_digest(self.COLUMN_TAGS[c], whole).view(np.int64).copy())
+            del whole
+        digests = _allreduce_sum(digests)
+        aux = self.p.ali_challenges(digests.numpy().view(np.uint64), n0)          # seed, z, beta — identical on every rank
+        self.ali_aux = aux
+        return self.p.ali_merge_shard(a, s, e, t, aux[1], rank * nl, n0)
+
+    # -- fri_build_transcript (fri.rs:231-312) ------------------------------------------------------------
+    def _shardable(self, l, n, prev_sharded):
+        W, L = self.W, len(self.schedule)
+        m = self.schedule[l] if l < L else 1
+        ar = pick_arity_for_layer(n, m)
+        if not prev_sharded or not hashed_arity(ar) or n % W:
+            return False
+        nl = n // W
+        return nl % ar == 0 and (l == L or nl % m == 0)
+
+    def commit(self, f0_local):
+        import numpy as np
+        p, rank, W, L = self.p, self.rank, self.W, len(self.schedule)
+        self.layers = []
+        sizes = [self.n0]
+        for m in self.schedule:
+            sizes.append(sizes[-1] // m)
+        self.z = [p.fri_sample_z(self.seed_z, l, sizes[l]) for l in range(L)]     # challenges do not depend on commitments (fri.rs:250)
+        # layers: fold while block-local, then all-gather once and continue replicated
+        cur, sharded = f0_local, True
+        for l in range(L + 1):
+            lay = _Layer(); lay.n = sizes[l]
+            m = self.schedule[l] if l < L else 1
+            lay.arity = pick_arity_for_layer(lay.n, m); lay.hashed = hashed_arity(lay.arity)
+            now = self._shardable(l, lay.n, sharded)
+            if sharded and not now:                                    # transition: every rank gets the whole (small) layer
+                cur = all_gather_rows(cur)
+            sharded = now
+            lay.sharded, lay.f = sharded, cur
+            self.layers.append(lay)
+            if l < L:
+                cur = p.fold(cur, self.z[l], m)                        # block-local: m divides the local length (or the layer is whole)
+        # commitments
+        roots = []
+        for l, lay in enumerate(self.layers):
+            m = self.schedule[l] if l < L else 1
+            params = p.params_for_arity(lay.arity)
+            nxt = self.layers[l + 1] if l < L else None
+            if lay.sharded:
+                nl = lay.n // W
+                if nxt is None:
+                    f_next = None
+                elif nxt.sharded:
+                    f_next = nxt.f
+                else:
+                    f_next = nxt.f[rank * (nl // m):(rank + 1) * (nl // m)]        # this block's parents inside the whole next layer
+                h = p.leaf_pair_hash(lay.f, f_next, m)                             # fri.rs:283, s = f_{l+1}[i/m]
+                stop = sharded_stop_len(nl, lay.arity)
+                lay.tree = p.merkle_build(params, lay.arity, l, h, nl, rank * nl, 0, stop)
+                top, nlev = p.merkle_last_level(lay.tree)
+                lay.nlev_local = nlev
+                lay.local_lens = [p.merkle_level_len(lay.tree, v) for v in range(nlev)]
+                allv = all_gather_rows(top)
+                lay.top = p.merkle_build(params, lay.arity, l, allv, allv.shape[0], 0, nlev - 1, 1)
+                rt, _ = p.merkle_last_level(lay.top)
+                roots.append(rt[0].cpu().numpy().view(np.uint64))
+            else:
+                n = lay.n
+                if lay.hashed:
+                    h = p.leaf_pair_hash(lay.f, nxt.f if nxt is not None else None, m)
+                    lay.tree = p.merkle_build(params, lay.arity, l, h, n, 0, 0, 1)
+                else:                                                               # commit_pairs(f_l, s_l), fri.rs:289
+                    if nxt is not None:
+                        idx = torch.arange(n, device=lay.f.device) // m
+                        s_l = nxt.f[idx].contiguous()
+                    else:
+                        s_l = p.zeros(n)                                            # fri.rs:266
+                    lay.tree = p.merkle_build_pairs(params, lay.arity, l, lay.f, s_l, n)
+                lay.top, lay.nlev_local, lay.local_lens = None, 0, []
+                rt, _ = p.merkle_last_level(lay.tree)
+                roots.append(rt[0].cpu().numpy().view(np.uint64))
+        self.roots = np.stack(roots)
+        return self.roots
+
+    # -- fri_prove_queries + encoding (fri.rs:355-466, 613-640) -------------------------------------------
+    def queries(self):
+        import numpy as np
+        p, rank, W = self.p, self.rank, self.W
+        plan = p.query_plan(self.roots, self.n0, self.schedule, self.r)
+        kind, which, level, index = plan.requests()
+        vals = np.zeros((len(kind), 4), np.uint64)
+        # group the requests this rank owns by source, one gather per group
+        groups = {}
+        for i in range(len(kind)):
+            lay = self.layers[int(which[i])]
+            idx = int(index[i])
+            if kind[i] == 0:
+                if lay.sharded:
+                    nl = lay.n // W
+                    owner, key, loc = idx // nl, ("f", int(which[i])), idx % nl
+                else:
+                    owner, key, loc = 0, ("f", int(which[i])), idx
+            else:
+                v = int(level[i])
+                if lay.sharded and v < lay.nlev_local - 1:
+                    ln = lay.local_lens[v]
+                    owner, key, loc = idx // ln, ("t", int(which[i]), v), idx % ln
+                elif lay.sharded:
+                    owner, key, loc = 0, ("top", int(which[i]), v - (lay.nlev_local - 1)), idx
+                else:
+                    owner, key, loc = 0, ("t", int(which[i]), v), idx
+            if owner == rank:
+                groups.setdefault(key, []).append((i, loc))
+        for key, items in groups.items():
+            pos = np.array([i for i, _ in items]); loc = np.array([j for _, j in items], dtype=np.int64)
+            lay = self.layers[key[1]]
+            if key[0] == "f":
+                got = lay.f[torch.from_numpy(loc).to(lay.f.device)].cpu().numpy().view(np.uint64)
+            elif key[0] == "t":
+                got = p.merkle_gather(lay.tree, key[2], loc)
+            else:
+                got = p.merkle_gather(lay.top, key[2], loc)
+            vals[pos] = got
+        vals = _allreduce_sum(torch.from_numpy(vals.view(np.int64))).numpy().view(np.uint64)
+        proof, est = plan.assemble(vals)
+        plan.free()
+        return proof, est
+
+    def free(self):
+        for lay in self.layers:
+            if lay.tree is not None:
+                self.p.merkle_free(lay.tree)
+            if lay.top is not None:
+                self.p.merkle_free(lay.top)
+        self.layers = []
+
+    def prove(self, a, s, e, t, f0_local=None):
+        """(proof bytes, size estimate); a, s, e, t: this rank's [n0/W, 4] blocks."""
+        import time
+        t0 = time.perf_counter()
+        if f0_local is None:
+            f0_local = self.build_f0(a, s, e, t)
+        self.p.sync(); t1 = time.perf_counter()
+        self.commit(f0_local)
+        self.p.sync(); t2 = time.perf_counter()
+        out = self.queries()
+        t3 = time.perf_counter()
+        self.timings = {"build_f0_ms": (t1 - t0) * 1e3, "fri_build_ms": (t2 - t1) * 1e3, "queries_encode_ms": (t3 - t2) * 1e3}
+        self.free()
+        return out

@@ -72,3 +72,33 @@ class HostCheck:
         out = np.zeros((n, 4), np.uint64)
         self.l.hc_hash_stream(h, mode, P(A(a)) if na else None, C.c_size_t(na), P(A(b)) if nb else None, C.c_size_t(nb), P(None if tag is None else A(tag)), C.c_size_t(n), P(out))
         return out[0] if n == 1 else out
+
+    # ---- query plan / assemble (fri_plan.hpp, host hasher) ----------------------------------------------
+    def fri_plan(self, tparams, roots, n0, schedule, r):
+        self.l.hc_fri_plan_create.restype = vp; self.l.hc_fri_plan_num_requests.restype = C.c_size_t; self.l.hc_fri_plan_assemble.restype = C.c_size_t
+        sch = np.ascontiguousarray(schedule, dtype=np.uint64)
+        h = self.l.hc_fri_plan_create(tparams, P(A(roots)), C.c_size_t(n0), P(sch), C.c_size_t(len(sch)), C.c_size_t(r))
+        if not h:
+            raise RuntimeError("plan failed")
+        return HcPlan(self, vp(h))
+
+
+class HcPlan:
+    def __init__(self, hc, h): self.hc, self.h = hc, h
+
+    def requests(self):
+        n = self.hc.l.hc_fri_plan_num_requests(self.h)
+        kind = np.zeros(n, np.uint32); which = np.zeros(n, np.uint32); level = np.zeros(n, np.uint32); index = np.zeros(n, np.uint64)
+        self.hc.l.hc_fri_plan_requests(self.h, P(kind), P(which), P(level), P(index)); return kind, which, level, index
+
+    def assemble(self, values):
+        v = A(values).reshape(-1, 4); est = C.c_size_t()
+        ln = self.hc.l.hc_fri_plan_assemble(self.h, P(v), C.c_size_t(v.shape[0]), None, C.c_size_t(0), C.byref(est))
+        if not ln:
+            raise RuntimeError("assemble failed")
+        buf = (C.c_uint8 * ln)()
+        self.hc.l.hc_fri_plan_assemble(self.h, P(v), C.c_size_t(v.shape[0]), buf, C.c_size_t(ln), C.byref(est))
+        return bytes(buf), est.value
+
+    def free(self):
+        if self.h: self.hc.l.hc_fri_plan_free(self.h); self.h = None

@@ -59,6 +59,42 @@ class CpuStandIn:
     def merkle_free(self, h): pass
     def sync(self): pass
 
+    # ---- block-local steps of the sharded prover (same method names as dist.HipProvider) ----------------
+    def _t(self, a): return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).copy())
+    def params_for_arity(self, arity): return None
+    def new(self, n): return torch.empty((n, 4), dtype=torch.int64)
+    def zeros(self, n): return torch.zeros((n, 4), dtype=torch.int64)
+    def fri_sample_z(self, seed_z, level, n): return self.o.fri_sample_z_ell(seed_z, level, n)
+    def fold(self, f, z, m): return self._t(self.o.fri_fold_layer(self._np(f), z, m))
+    def leaf_pair_hash(self, f, f_next, m): return self._t(self.o.leaf_pair_hash(self._np(f), None if f_next is None else self._np(f_next.contiguous()), m))
+    def merkle_build_pairs(self, params, arity, tree_label, f, cp, n):
+        t = self.o.merkle_build(arity, tree_label, self._np(f), self._np(cp)); lv = [t.level(v) for v in range(t.num_levels())]; t.free(); return lv
+    def merkle_num_levels(self, h): return len(h)
+    def merkle_level_len(self, h, lvl): return h[lvl].shape[0]
+    def merkle_gather(self, h, lvl, idx): return h[lvl][np.asarray(idx, dtype=np.int64)]
+    def column_digest(self, tag, col): return self.o.tr_hash_fields_tagged(tag, self._np(col))
+    def ali_challenges(self, digests, n0):
+        # ali_sample_z_beta_fs (fri.rs:511-533) from primitives: seed = H("ALI/seed", digests || n0); ChaCha12 seeded by H("ALI/DEEP", seed || n0)
+        o = self.o
+        seed = o.tr_hash_fields_tagged(b"ALI/seed", np.vstack([digests, o.from_u64(n0)[None, :]]))
+        fused = o.tr_hash_fields_tagged(b"ALI/DEEP", np.vstack([seed[None, :], o.from_u64(n0)[None, :]]))
+        u = self.hc.chacha12_u64s(o.to_bytes_le(fused), 64)
+        beta = o.from_u64(int(u[0])); one = o.from_u64(1); z = None
+        for x in u[1:]:
+            c = o.from_u64(int(x))
+            if int(x) != 0 and not (o.pow(c, n0) == one).all(): z = c; break
+        return np.stack([seed, z, beta])
+    def ali_merge_shard(self, a, s, e, t, z, j0, n_global):
+        o = self.o; a, s, e, t = (self._np(x) for x in (a, s, e, t)); w = o.domain_omega(n_global); out = np.zeros_like(a)
+        wj = o.pow(w, j0)
+        for i in range(a.shape[0]):
+            phi = o.sub(o.add(o.mul(a[i], s[i]), e[i]), t[i])
+            out[i] = o.mul(phi, o.inv(o.sub(wj, z))); wj = o.mul(wj, w)
+        return self._t(out)
+    def query_plan(self, roots, n0, schedule, r):
+        if not hasattr(self, "tparams"): self.tparams = self.hc.params(1)
+        return self.hc.fri_plan(self.tparams, roots, n0, schedule, r)
+
 
 def _worker(rank, world, port, log_n, log_rows, inverse, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -106,6 +142,39 @@ def test_six_step_ntt_and_sharded_merkle_world2(log_n, log_rows, inverse):
     res = [q.get(timeout=240) for _ in procs]
     for p in procs: p.join(60)
     assert sorted(res) == [(0, True, True, True, True), (1, True, True, True, True)], res
+
+
+def _prove_worker(rank, world, port, log_n0, schedule, r, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stark_mlwe_amd import dist as sd
+        prov = CpuStandIn(); o = prov.o
+        n0 = 1 << log_n0; nl = n0 // world
+        cols = [o.synth_column(0x5EED0000 + log_n0, c, 0, n0) for c in range(4)]
+        mine = [prov._t(c[rank * nl:(rank + 1) * nl]) for c in cols]
+        dp = sd.DistProver(prov, n0, schedule, r, 0xDEEFBAAD)
+        proof, est = dp.prove(*mine)
+        ref = o.deep_fri_prove(*cols, n0, schedule, r, 0xDEEFBAAD)
+        want = ref.bytes(); west = ref.size_estimate(); ref.free()
+        sharded = [bool(l.sharded) for l in dp.layers] if dp.layers else None
+        q.put((rank, proof == want, est == west, o.deep_fri_verify(proof, schedule, r, 0xDEEFBAAD)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("log_n0,schedule,r", [(9, [16, 8], 6), (10, [8, 8, 8], 5), (7, [16, 8], 3)])
+def test_sharded_prove_world2_matches_reference_bytes(log_n0, schedule, r):
+    """One trace block-sharded over 2 ranks -> the SAME canonical proof bytes as the oracle's prove of the whole trace."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + log_n0
+    procs = [ctx.Process(target=_prove_worker, args=(r_, 2, port, log_n0, schedule, r, q)) for r_ in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs: p.join(60)
+    assert sorted(res) == [(0, True, True, 1), (1, True, True, 1)], res
 
 
 def test_sharded_stop_len():

@@ -54,3 +54,42 @@ def test_two_ranks_share_one_gpu(log_n, log_rows):
     res = [q.get(timeout=500) for _ in procs]
     for p in procs: p.join(120)
     assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
+
+
+def _prove_worker(rank, world, port, log_n0, schedule, r, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib
+        from stark_mlwe_amd import dist as sd
+        from stark_mlwe_amd.api import Context, DeepFriParams
+        torch.cuda.set_device(0)
+        ctx = Context(0); o = oracle_lib.Oracle(); prov = sd.HipProvider(ctx)
+        n0 = 1 << log_n0; nl = n0 // world
+        cols = [o.synth_column(0x5EED0000 + log_n0, c, 0, n0) for c in range(4)]
+        mine = [torch.from_numpy(c[rank * nl:(rank + 1) * nl].view(np.int64).copy()).cuda() for c in cols]
+        dp = sd.DistProver(prov, n0, schedule, r, 0xDEEFBAAD)
+        proof, est = dp.prove(*mine)
+        single, est1, _ = ctx.deep_fri_prove(*cols, n0, DeepFriParams(schedule, r, 0xDEEFBAAD))      # the one-GPU product path on the whole trace
+        ok_oracle = None
+        if log_n0 <= 12:
+            ref = o.deep_fri_prove(*cols, n0, schedule, r, 0xDEEFBAAD); ok_oracle = ref.bytes() == proof; ref.free()
+        ctx.close()
+        q.put((rank, proof == single, est == est1, ok_oracle, o.deep_fri_verify(proof, schedule, r, 0xDEEFBAAD)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("log_n0,schedule,r", [(12, [16, 16, 8], 32), (16, [16, 16, 8], 32)])
+def test_sharded_prove_two_ranks_one_gpu(log_n0, schedule, r):
+    """One trace block-sharded over 2 ranks (sharing the GPU): the same proof bytes as the one-GPU prove and the oracle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000) + log_n0
+    procs = [ctx.Process(target=_prove_worker, args=(r_, 2, port, log_n0, schedule, r, q)) for r_ in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs: p.join(120)
+    want_oracle = True if log_n0 <= 12 else None
+    assert sorted(res) == [(0, True, True, want_oracle, 1), (1, True, True, want_oracle, 1)], res
