@@ -93,3 +93,36 @@ def test_sharded_prove_two_ranks_one_gpu(log_n0, schedule, r):
     for p in procs: p.join(120)
     want_oracle = True if log_n0 <= 12 else None
     assert sorted(res) == [(0, True, True, want_oracle, 1), (1, True, True, want_oracle, 1)], res
+
+
+def _rccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x = (torch.arange(4 * 64 * 4, dtype=torch.int64, device="cuda") * 0x9E3779B97F4A7C15 % (1 << 62)).view(4 * 64, 4)
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out.view(-1), x.contiguous().view(-1))                 # the six-step transpose call (int64 limbs)
+        ok_a2a = bool((out == x).all())
+        lst = [torch.empty_like(x)]
+        dist.all_gather(lst, x.contiguous()); ok_ag = bool((lst[0] == x).all())       # tree tops / small layers
+        y = x.clone(); dist.all_reduce(y); ok_ar = bool((y == x).all())               # the query value table (int64 SUM)
+        parts = [torch.empty_like(x)]
+        dist.gather(x.contiguous(), parts, dst=0); ok_g = bool((parts[0] == x).all()) # columns to their sponge rank
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier(); torch.cuda.synchronize()
+        q.put((ok_a2a, ok_ag, ok_ar, ok_g, float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_accept_our_tensors():
+    """The exact RCCL calls of stark_mlwe_amd/dist.py and bench.py (dtype int64 limbs on the device) on a
+    one-rank communicator: catches API / dtype refusals that only the nccl backend would raise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(30900 + os.getpid() % 1000, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert res == (True, True, True, True, 1.5), res
