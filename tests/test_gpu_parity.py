@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path through the C-ABI against the oracle on identical seeded inputs
 (bit-exact: everything here is exact integer arithmetic), plus size-independent properties at the
 BASELINE sizes.  Needs an MI355X: `pytest -m gpu`."""
+import ctypes as C
 import struct
 
 import numpy as np
@@ -499,3 +500,25 @@ def test_gpu_proof_tamper_rejected(gpu_ctx, oracle):
         bad = bytearray(got); bad[pos] ^= 1
         rejected += oracle.deep_fri_verify(bytes(bad), sched, r, 0xDEEFBAAD) != 1
     assert rejected >= 5      # roots, siblings, opened values: caught; the trailing (n0, omega) words are not read by the reference's verifier
+
+
+@pytest.mark.parametrize("log_n0", [20, 23])
+def test_full_size_proof_accepted_by_reference_verifier(gpu_ctx, oracle, log_n0):
+    """BASELINE sizes (2^20 trace; 2^23 = its blow-up-8 extension): the commit + query phases on the GPU, then
+    deep_fri_verify (fri.rs:643-762, oracle restatement) on the proof bytes — every opened leaf, every Merkle
+    multiproof up to the L+1 roots and the final layer must check out; the sharded code path must agree byte for byte."""
+    import torch
+    from stark_mlwe_amd import dist as sd
+    n0, sched, r = 1 << log_n0, [16, 16, 8], 32
+    f0 = torch.empty((n0, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, 0x5EED0000 + log_n0, 5, 0, n0, C.c_void_p(f0.data_ptr())))
+    sch = np.ascontiguousarray(sched, dtype=np.uint64); h = C.c_void_p()
+    gpu_ctx._chk(gpu_ctx.lib.stark_deep_fri_prove_dev(gpu_ctx.h, None, None, None, None, C.c_void_p(f0.data_ptr()), n0, sch.ctypes.data_as(C.c_void_p), 3, r, 0xDEEFBAAD, C.byref(h)))
+    proof, est = gpu_ctx._proof_out(h)
+    assert oracle.deep_fri_verify(proof, sched, r, 0xDEEFBAAD) == 1
+    assert oracle.proof_size_estimate_from_bytes(proof) == est
+    dp = sd.DistProver(sd.HipProvider(gpu_ctx), n0, sched, r, 0xDEEFBAAD)
+    proof2, est2 = dp.prove(None, None, None, None, f0_local=f0)
+    assert proof2 == proof and est2 == est
+    bad = bytearray(proof); bad[len(bad) // 2] ^= 0x10
+    assert oracle.deep_fri_verify(bytes(bad), sched, r, 0xDEEFBAAD) == 0
