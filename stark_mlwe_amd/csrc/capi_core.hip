@@ -36,12 +36,20 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     const host::KernelConsts& k = P->kc;
     std::vector<fr_t> blob; auto put = [&](const std::vector<fr_t>& v) { size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
     size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds), o_mpre = put(k.mds_pre), o_gam = put(k.gamma);
+    // radix-2^29 multiplier tables (fr29.hpp), appended to the same device blob as raw words
+    const size_t o_29 = blob.size();
+    { std::vector<uint32_t> w29; for (auto* v : {&k.lu29, &k.lu_pre29, &k.row0_29, &k.sparse29, &k.gamma29}) w29.insert(w29.end(), v->begin(), v->end());
+      while (w29.size() % 8) w29.push_back(0);
+      blob.resize(o_29 + w29.size() / 8); memcpy((void*)(blob.data() + o_29), w29.data(), w29.size() * 4); }
     STARK_HIP(ctx, hipMalloc((void**)&P->blob, blob.size() * sizeof(fr_t)));
     STARK_HIP(ctx, hipMemcpyAsync(P->blob, blob.data(), blob.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     P->dev.t = k.t; P->dev.rf = k.rf; P->dev.rp = k.rp;
     P->dev.rc_full = P->blob + o_rcf; P->dev.rc_partial = P->blob + o_rcp; P->dev.lu = P->blob + o_lu; P->dev.lu_pre = P->blob + o_pre;
     P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds; P->dev.mds_pre = P->blob + o_mpre; P->dev.gamma = P->blob + o_gam;
+    { const uint32_t* b29 = reinterpret_cast<const uint32_t*>(P->blob + o_29);
+      P->dev.lu29 = b29; P->dev.lu_pre29 = b29 + k.lu29.size(); P->dev.row0_29 = P->dev.lu_pre29 + k.lu_pre29.size();
+      P->dev.sparse29 = P->dev.row0_29 + k.row0_29.size(); P->dev.gamma29 = P->dev.sparse29 + k.sparse29.size(); }
     return STARK_OK;
 }
 static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c, stark_params** out) {
@@ -136,13 +144,16 @@ static int32_t ctx_leaf_init(stark_ctx* ctx, fr_t** out) {
         // closed form of round 0 for the wave-pair kernel: K_i = sum_{j != 4,5} M[i][j] * (init_j + rc0_j)^5, then columns 4 and 5 of M
         stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
         const host::PoseidonConsts& c = tp->ref;
-        fr_t blob[17 + 51];
+        fr_t blob[17 + 51 + 40];                       // + columns 4, 5 of M as 34 x 9 words in radix 2^29 (306 words = 38.25 elements)
+        for (auto& x : blob) x = host::h_zero();
         for (int j = 0; j < 17; ++j) blob[j] = init[j];
         fr_t x[17]; for (int j = 0; j < 17; ++j) x[j] = fr_pow5<PallasFr>(host::h_add(init[j], c.rc_full[j]));
         for (int i = 0; i < 17; ++i) {
             fr_t k = host::h_zero();
             for (int j = 0; j < 17; ++j) if (j != 4 && j != 5) k = host::h_add(k, host::h_mul(c.mds[(size_t)i * 17 + j], x[j]));
             blob[17 + i] = k; blob[34 + i] = c.mds[(size_t)i * 17 + 4]; blob[51 + i] = c.mds[(size_t)i * 17 + 5];
+            uint32_t* m45 = reinterpret_cast<uint32_t*>(&blob[68]);
+            fr29_const_from<PallasFr>(c.mds[(size_t)i * 17 + 4], m45 + 9 * i); fr29_const_from<PallasFr>(c.mds[(size_t)i * 17 + 5], m45 + 9 * (17 + i));
         }
         STARK_HIP(ctx, hipMalloc((void**)&ctx->leaf_init, sizeof(blob)));
         STARK_HIP(ctx, hipMemcpyAsync(ctx->leaf_init, blob, sizeof(blob), hipMemcpyHostToDevice, ctx->stream));

@@ -1,0 +1,114 @@
+// stark_mlwe_amd/csrc/fr29.hpp — carry-free sums of products in radix 2^29 (gfx950: integer-VALU bound kernels).
+//
+// Why: in radix 2^32 every 32x32 partial product of a dot product costs TWO half-rate instructions
+// (v_mad_u64_u32 + v_addc_co_u32: the 64-bit column accumulator can overflow on every add; measured
+// 10.4 nominal cycles per pair at 2 waves/SIMD, profiles/r01_mac_carry_patterns.jsonl).  With 29-bit limbs
+// a partial product is < 2^58, so a 64-bit column holds 63 of them: 9 x 9 = 81 products per term but
+// NO carry instruction (5.85 cycles each) — 474 instead of 666 cycles per term, and the column walk of the
+// reduction has no carry words either.
+//
+// Domain trick: data stays in the ark-ff representation x*R mod r, R = 2^256 (nothing changes at the ABI or
+// in LDS).  The CONSTANT operand of every dot product (MDS / sparse-matrix entries) is stored as
+// c*R' mod r with R' = 2^261 = 2^(9*29), split into nine 29-bit limbs; the Montgomery reduction below
+// divides by R', so  sum_i (c_i R')(x_i R) / R' = (sum_i c_i x_i) R  — the result is again in the R domain.
+// r = 1 (mod 2^29) in both fields, so the quotient digit is m = -t mod 2^29 with no multiply.
+//
+// Bounds (operands reduced, < r < 2^255): a column gains < 9 * 2^58 per term; normalise (carry pass) after at
+// most 7 terms, reduce after at most 6 terms since the last normalisation (the reduction adds < 9 * 2^58 more
+// per column).  For a sum of K <= 64 terms the Montgomery step leaves < (K/128 + 1) r < 2r: ONE conditional
+// subtraction.  Portable C++ (host build for the CPU checks; on the device the products compile to
+// v_mad_u64_u32 with the 64-bit add folded in).
+#pragma once
+#include "fr.hpp"
+
+namespace stark {
+
+constexpr uint32_t FR_M29 = (1u << 29) - 1;
+struct fr29_t { uint32_t l[9]; };             // value = sum l[i] * 2^(29 i), l[i] < 2^29
+struct fr_wide29 { uint64_t c[18]; };         // column sums, weight 2^(29 k)
+
+template <class F> constexpr uint32_t fr_p29(int i) {      // limb i of the modulus in radix 2^29
+    const int lo = 29 * i, w = lo >> 5, s = lo & 31;
+    const uint64_t x = (w < 8 ? (uint64_t)F::P(w) : 0ull) | (w + 1 < 8 ? ((uint64_t)F::P(w + 1) << 32) : 0ull);
+    return (uint32_t)(x >> s) & FR_M29;
+}
+
+FR_HD fr29_t fr29_unpack(const fr_t& x) {
+    fr29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int lo = 29 * i, w = lo >> 5, s = lo & 31;
+        uint32_t v = x.v[w] >> s;
+        if (s > 3 && w + 1 < 8) v |= x.v[w + 1] << (32 - s);
+        r.l[i] = v & FR_M29;
+    }
+    return r;
+}
+FR_HD void fr_wide29_zero(fr_wide29& w) {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) w.c[k] = 0;
+}
+// W += a * b, a = nine 29-bit limbs (a constant in the R' domain), b unpacked data.
+// Device: the constant tables are never written by a kernel and their address is wave-uniform, but after the
+// first workgroup barrier the compiler can no longer prove "not clobbered" and falls back to per-lane vector
+// loads (a VMEM round trip in front of every term).  Reading them through the constant address space keeps
+// them on the scalar data path (s_load -> SGPR operand of the MAC).
+FR_HD void fr_wide29_mac(fr_wide29& w, const uint32_t* __restrict__ a_, const fr29_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
+    cptr_t a = (cptr_t)a_;
+#else
+    const uint32_t* a = a_;
+#endif
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t ai = a[i];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w.c[i + j] += (uint64_t)ai * b.l[j];
+    }
+}
+// carry pass: columns 0..16 back below 2^29, the excess moves up (column 17 absorbs the top)
+FR_HD void fr_wide29_norm(fr_wide29& w) {
+#pragma unroll
+    for (int k = 0; k < 17; ++k) { w.c[k + 1] += w.c[k] >> 29; w.c[k] &= FR_M29; }
+}
+// Montgomery reduction by R' = 2^261 and return to eight 32-bit limbs, fully reduced.
+template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint64_t t = w.c[k];
+        const uint32_t m = (0u - (uint32_t)t) & FR_M29;            // t + m * r == 0 (mod 2^29) because r == 1 (mod 2^29)
+        w.c[k + 1] += (t + m) >> 29;
+#pragma unroll
+        for (int j = 1; j < 9; ++j)
+            if (fr_p29<F>(j) != 0) w.c[k + j] += (uint64_t)m * fr_p29<F>(j);
+    }
+    // columns 9..17 hold the quotient: carry-propagate into 29-bit limbs, then regroup into 32-bit words
+    uint32_t l[9]; uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const uint64_t v = w.c[9 + i] + carry; l[i] = i < 8 ? ((uint32_t)v & FR_M29) : (uint32_t)v; carry = v >> 29; }
+    uint32_t t[9];
+#pragma unroll
+    for (int wd = 0; wd < 8; ++wd) {
+        const int lo = 32 * wd, i = lo / 29, s = lo - 29 * i;        // word wd starts at bit s of limb i
+        uint32_t v = l[i] >> s;
+        if (i + 1 < 9) v |= l[i + 1] << (29 - s);
+        if (29 - s + 29 < 32 && i + 2 < 9) v |= l[i + 2] << (58 - s);
+        t[wd] = v;
+    }
+    t[8] = 0;                                                       // the value is below 2r < 2^256
+    fr_cond_sub<F>(t, t[8]);
+    fr_t z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z.v[i] = t[i];
+    return z;
+}
+
+// Host side: the nine limbs of c * R' mod r for a constant given in the R domain (c * R mod r).
+template <class F> inline void fr29_const_from(const fr_t& c_R, uint32_t out[9]) {
+    const fr_t c32 = fr_mul_portable<F>(c_R, fr_from_u64<F>(32));   // (cR)(32R)/R = 32 c R = c R'
+    const fr29_t u = fr29_unpack(c32);
+    for (int i = 0; i < 9; ++i) out[i] = u.l[i];
+}
+
+}  // namespace stark

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include "fr.hpp"
+#include "fr29.hpp"
 
 namespace stark {
 namespace host {
@@ -198,8 +199,15 @@ struct KernelConsts {
     std::vector<fr_t> mds;              // t*t reference form (cooperative kernel: full rounds)
     std::vector<fr_t> mds_pre;          // t*t dense B_1*M (cooperative kernel: last first-half full round)
     std::vector<fr_t> gamma;            // (rp/4)*6: blocks of 4 partial rounds, gamma[q(q-1)/2+p] = sum_j u_{q,j} w_{p,j} (p < q)
+    // the multiplier tables of every dot product again, as nine 29-bit limbs of c*2^261 mod r per entry (fr29.hpp)
+    std::vector<uint32_t> lu29, lu_pre29, row0_29, sparse29, gamma29;
     bool ok = false;
 };
+inline std::vector<uint32_t> to_radix29(const std::vector<fr_t>& v) {
+    std::vector<uint32_t> o(v.size() * 9);
+    for (size_t i = 0; i < v.size(); ++i) fr29_const_from<PF>(v[i], &o[9 * i]);
+    return o;
+}
 // Gauss-Jordan inverse of an n x n matrix (row-major); returns false when singular.
 inline bool mat_inverse(std::vector<fr_t> a, int n, std::vector<fr_t>& inv) {
     inv.assign((size_t)n * n, h_zero()); for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = h_one();
@@ -266,6 +274,7 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     if (!lu_pack(c.mds, t, k.lu)) return k;
     if (!lu_pack(cur, t, k.lu_pre)) return k;
     k.mds_pre = cur;
+    k.lu29 = to_radix29(k.lu); k.lu_pre29 = to_radix29(k.lu_pre); k.row0_29 = to_radix29(k.row0); k.sparse29 = to_radix29(k.sparse); k.gamma29 = to_radix29(k.gamma);
     k.ok = true;
     return k;
 }

@@ -22,6 +22,7 @@ static void bind(HcParams* P) {
     P->kc = host::make_kernel_consts(P->ref);
     P->dev.t = P->kc.t; P->dev.rf = P->kc.rf; P->dev.rp = P->kc.rp; P->dev.rc_full = P->kc.rc_full.data(); P->dev.rc_partial = P->kc.rc_partial.data();
     P->dev.lu = P->kc.lu.data(); P->dev.lu_pre = P->kc.lu_pre.data(); P->dev.row0 = P->kc.row0.data(); P->dev.sparse = P->kc.sparse.data(); P->dev.mds = P->kc.mds.data(); P->dev.mds_pre = P->kc.mds_pre.data(); P->dev.gamma = P->kc.gamma.data();
+    P->dev.lu29 = P->kc.lu29.data(); P->dev.lu_pre29 = P->kc.lu_pre29.data(); P->dev.row0_29 = P->kc.row0_29.data(); P->dev.sparse29 = P->kc.sparse29.data(); P->dev.gamma29 = P->kc.gamma29.data();
 }
 
 extern "C" {
@@ -40,11 +41,18 @@ int hc_fr_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* 
     }
     st4(out, z); return 0;
 }
-// sum_i a_i*b_i through the product's wide accumulator (DotAcc: one reduction per <= 24 terms)
+// sum_i a_i*b_i through the product's dot-product accumulator (DotAcc: radix-2^29 constants, carry pass every 6 terms,
+// chunks of 60) and, for comparison, through the radix-2^32 wide accumulator the cooperative kernels use (mode 1)
 int hc_wide_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     DotAcc d; d.init();
-    for (size_t i = 0; i < n; ++i) d.mac(ld4(a + 4 * i), ld4(b + 4 * i));
+    for (size_t i = 0; i < n; ++i) { uint32_t c[9]; fr29_const_from<PF>(ld4(a + 4 * i), c); d.mac(c, ld4(b + 4 * i)); }
     st4(out, d.finish()); return 0;
+}
+int hc_wide_dot32(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    if (n > 24) return -1;
+    fr_wide w; fr_wide_zero(w);
+    for (size_t i = 0; i < n; ++i) fr_wide_mac_f<PF>(w, ld4(a + 4 * i), ld4(b + 4 * i));
+    st4(out, fr_wide_reduce<PF>(w)); return 0;
 }
 int hc_blake3(const uint8_t* p, size_t n, uint8_t* out32) { host::Blake3::hash(p, n, out32); return 0; }
 int hc_chacha12_u64s(const uint8_t* seed32, size_t n, uint64_t* out) { host::ChaCha12Rng r(seed32); for (size_t i = 0; i < n; ++i) out[i] = r.next_u64(); return 0; }

@@ -19,6 +19,7 @@
 // can be instantiated with a plain array on the host by the host-check library (CPU unit tests).
 #pragma once
 #include "fr.hpp"
+#include "fr29.hpp"
 #include "dev_common.hpp"
 #include "poseidon_params.hpp"
 
@@ -33,33 +34,36 @@ struct ArrayState {
     FR_HD void st(int j, const fr_t& x) const { a[j] = x; }
 };
 
-// Dot product with one Montgomery reduction per <= 24 terms (fr_reduce_wide_tail covers sums of up to
-// 27 products; wide states, t = 33..129, have longer rows and are reduced in chunks).
+// Dot product  sum_i c_i * x_i  with ONE Montgomery reduction: constants as nine 29-bit limbs in the 2^261
+// domain, carry-free column sums (fr29.hpp).  A carry pass every 6 terms keeps the 64-bit columns in range;
+// rows longer than 60 terms (t = 65, 129) are reduced in chunks.
 struct DotAcc {
-    fr_wide w; fr_t sum; int cnt; bool have_sum;
-    FR_HD void init() { fr_wide_zero(w); cnt = 0; have_sum = false; }
-    FR_HD void mac(const fr_t& a, const fr_t& b) {
-        fr_wide_mac_f<PF>(w, a, b);
-        if (++cnt == 24) { fr_t r = fr_wide_reduce<PF>(w); sum = have_sum ? fr_add<PF>(sum, r) : r; have_sum = true; fr_wide_zero(w); cnt = 0; }
+    fr_wide29 w; fr_t sum; int since, total; bool have_sum;
+    FR_HD void init() { fr_wide29_zero(w); since = 0; total = 0; have_sum = false; }
+    FR_HD void mac(const uint32_t* __restrict__ c29, const fr_t& x) {
+        if (since == 6) { fr_wide29_norm(w); since = 0; }
+        fr_wide29_mac(w, c29, fr29_unpack(x)); ++since;
+        if (++total == 60) { fr_t r = fr_wide29_reduce<PF>(w); sum = have_sum ? fr_add<PF>(sum, r) : r; have_sum = true; fr_wide29_zero(w); since = 0; total = 0; }
     }
     FR_HD fr_t finish() {
-        if (!have_sum) return fr_wide_reduce<PF>(w);
-        return cnt ? fr_add<PF>(sum, fr_wide_reduce<PF>(w)) : sum;
+        if (!have_sum) return fr_wide29_reduce<PF>(w);
+        return total ? fr_add<PF>(sum, fr_wide29_reduce<PF>(w)) : sum;
     }
 };
+FR_HD const uint32_t* c29(const uint32_t* base, size_t idx) { return base + 9 * idx; }
 
 // y = L*(U*x) in place.  U: row i needs x[j>=i] (top-down); unit-lower L: row i needs y[j<i] (bottom-up).
 // Every row is a dot product with wave-uniform constants: the 64-MAC partial products of all its terms
 // are summed in one wide accumulator and reduced once (fr.hpp "wide").
-template <class S> FR_HD void apply_lu(const S& s, const fr_t* lu, int t) {
+template <class S> FR_HD void apply_lu(const S& s, const uint32_t* lu, int t) {
     for (int i = 0; i < t; ++i) {
         DotAcc d; d.init();
-        for (int j = i; j < t; ++j) d.mac(lu[i * t + j], s.ld(j));
+        for (int j = i; j < t; ++j) d.mac(c29(lu, i * t + j), s.ld(j));
         s.st(i, d.finish());
     }
     for (int i = t - 1; i >= 1; --i) {
         DotAcc d; d.init();
-        for (int j = 0; j < i; ++j) d.mac(lu[i * t + j], s.ld(j));
+        for (int j = 0; j < i; ++j) d.mac(c29(lu, i * t + j), s.ld(j));
         s.st(i, fr_add<PF>(s.ld(i), d.finish()));
     }
 }
@@ -69,7 +73,7 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
     const int t = P.t, half = P.rf / 2;
     for (int r = 0; r < half; ++r) {
         for (int j = 0; j < t; ++j) s.st(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));
-        apply_lu(s, (r == half - 1) ? P.lu_pre : P.lu, t);
+        apply_lu(s, (r == half - 1) ? P.lu_pre29 : P.lu29, t);
     }
     // Partial rounds in blocks of 4 (rp is a multiple of 4 for every supported width).  Within a block the
     // lanes 1..t-1 stay at their block-start value s_j; round q of the block computes
@@ -79,27 +83,27 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
     fr_t s0 = s.ld(0);
     const int w = 2 * t - 1;
     for (int b = 0; b < P.rp / 4; ++b) {
-        const fr_t* sp = P.sparse + (size_t)(4 * b) * w;
-        const fr_t* g = P.gamma + (size_t)b * 6;
+        const uint32_t* sp = c29(P.sparse29, (size_t)(4 * b) * w);
+        const uint32_t* g = c29(P.gamma29, (size_t)b * 6);
         fr_t x0, x1, x2, x3;
 #define STARK_PARTIAL_ROUND(q, XQ)                                                              \
         {                                                                                       \
             XQ = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                           \
             DotAcc acc; acc.init();                                                             \
-            acc.mac(sp[q * w], XQ);                                                             \
-            if (q > 0) acc.mac(g[q * (q - 1) / 2 + 0], x0);                                      \
-            if (q > 1) acc.mac(g[q * (q - 1) / 2 + 1], x1);                                      \
-            if (q > 2) acc.mac(g[q * (q - 1) / 2 + 2], x2);                                      \
-            for (int j = 1; j < t; ++j) acc.mac(sp[q * w + j], s.ld(j));                         \
+            acc.mac(c29(sp, q * w), XQ);                                                        \
+            if (q > 0) acc.mac(c29(g, q * (q - 1) / 2 + 0), x0);                                 \
+            if (q > 1) acc.mac(c29(g, q * (q - 1) / 2 + 1), x1);                                 \
+            if (q > 2) acc.mac(c29(g, q * (q - 1) / 2 + 2), x2);                                 \
+            for (int j = 1; j < t; ++j) acc.mac(c29(sp, q * w + j), s.ld(j));                    \
             s0 = acc.finish();                                                                  \
         }
         STARK_PARTIAL_ROUND(0, x0) STARK_PARTIAL_ROUND(1, x1) STARK_PARTIAL_ROUND(2, x2) STARK_PARTIAL_ROUND(3, x3)
 #undef STARK_PARTIAL_ROUND
         for (int j = 1; j < t; ++j) {
-            fr_wide u; fr_wide_zero(u);
-            fr_wide_mac_f<PF>(u, sp[0 * w + t - 1 + j], x0); fr_wide_mac_f<PF>(u, sp[1 * w + t - 1 + j], x1);
-            fr_wide_mac_f<PF>(u, sp[2 * w + t - 1 + j], x2); fr_wide_mac_f<PF>(u, sp[3 * w + t - 1 + j], x3);
-            s.st(j, fr_add<PF>(s.ld(j), fr_wide_reduce<PF>(u)));
+            DotAcc u; u.init();
+            u.mac(c29(sp, 0 * w + t - 1 + j), x0); u.mac(c29(sp, 1 * w + t - 1 + j), x1);
+            u.mac(c29(sp, 2 * w + t - 1 + j), x2); u.mac(c29(sp, 3 * w + t - 1 + j), x3);
+            s.st(j, fr_add<PF>(s.ld(j), u.finish()));
         }
     }
     s.st(0, s0);
@@ -107,10 +111,10 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
         for (int j = 0; j < t; ++j) s.st(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));
         if (only0 && r == P.rf - 1) {
             DotAcc acc; acc.init();
-            for (int j = 0; j < t; ++j) acc.mac(P.row0[j], s.ld(j));
+            for (int j = 0; j < t; ++j) acc.mac(c29(P.row0_29, j), s.ld(j));
             return acc.finish();
         }
-        apply_lu(s, P.lu, t);
+        apply_lu(s, P.lu29, t);
     }
     return s.ld(0);
 }

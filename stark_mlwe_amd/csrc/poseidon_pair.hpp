@@ -53,20 +53,22 @@ struct PairState {
 
 // In-place y = L*(U*x) over the shared state; one barrier per step.  Ends with the state consistent.
 template <int T>
-__device__ __forceinline__ void pair_apply_lu(const PairState& s, const fr_t* lu) {
+__device__ __forceinline__ void pair_apply_lu(const PairState& s, const uint32_t* lu) {
     const int yo = s.isY ? 1 : 0;
+#pragma unroll 1
     for (int k = 0; 2 * k < T; ++k) {                       // U, top-down: rows 2k (X) and 2k+1 (Y)
         const int i = 2 * k + yo; const bool have = i < T;
         fr_t res;
-        if (have) { fr_wide w; fr_wide_zero(w); for (int j = i; j < T; ++j) fr_wide_mac_f<PF>(w, lu[i * T + j], s.ld(j)); res = fr_wide_reduce<PF>(w); }
+        if (have) { DotAcc w; w.init(); _Pragma("unroll 1") for (int j = i; j < T; ++j) w.mac(c29(lu, i * T + j), s.ld(j)); res = w.finish(); }
         __syncthreads();
         if (have) s.sto(i, res);
     }
     __syncthreads();
+#pragma unroll 1
     for (int k = 0; T - 1 - 2 * k >= 1; ++k) {              // unit-lower L, bottom-up: rows T-1-2k (X) and T-2-2k (Y)
         const int i = T - 1 - 2 * k - yo; const bool have = i >= 1;
         fr_t res;
-        if (have) { fr_wide w; fr_wide_zero(w); for (int j = 0; j < i; ++j) fr_wide_mac_f<PF>(w, lu[i * T + j], s.ld(j)); res = fr_add<PF>(s.ld(i), fr_wide_reduce<PF>(w)); }
+        if (have) { DotAcc w; w.init(); _Pragma("unroll 1") for (int j = 0; j < i; ++j) w.mac(c29(lu, i * T + j), s.ld(j)); res = fr_add<PF>(s.ld(i), w.finish()); }
         __syncthreads();
         if (have) s.sto(i, res);
     }
@@ -81,12 +83,12 @@ __device__ __forceinline__ void pair_sbox_full(const PairState& s, const fr_t* r
 
 // s_j += w_{0,j} x0 + w_{1,j} x1 + w_{2,j} x2 + w_{3,j} x3   (one reduction)
 template <int T>
-__device__ __forceinline__ fr_t pair_lane_update(const fr_t* sp, int j, const fr_t& base, const fr_t& x0, const fr_t& x1, const fr_t& x2, const fr_t& x3) {
+__device__ __forceinline__ fr_t pair_lane_update(const uint32_t* sp, int j, const fr_t& base, const fr29_t& x0, const fr29_t& x1, const fr29_t& x2, const fr29_t& x3) {
     constexpr int W = 2 * T - 1;
-    fr_wide u; fr_wide_zero(u);
-    fr_wide_mac_f<PF>(u, sp[0 * W + T - 1 + j], x0); fr_wide_mac_f<PF>(u, sp[1 * W + T - 1 + j], x1);
-    fr_wide_mac_f<PF>(u, sp[2 * W + T - 1 + j], x2); fr_wide_mac_f<PF>(u, sp[3 * W + T - 1 + j], x3);
-    return fr_add<PF>(base, fr_wide_reduce<PF>(u));
+    fr_wide29 u; fr_wide29_zero(u);
+    fr_wide29_mac(u, c29(sp, 0 * W + T - 1 + j), x0); fr_wide29_mac(u, c29(sp, 1 * W + T - 1 + j), x1);
+    fr_wide29_mac(u, c29(sp, 2 * W + T - 1 + j), x2); fr_wide29_mac(u, c29(sp, 3 * W + T - 1 + j), x3);
+    return fr_add<PF>(base, fr_wide29_reduce<PF>(u));
 }
 
 // One permutation by the wave pair.  Precondition: state consistent (a barrier since the last write).
@@ -98,52 +100,60 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
     const int half = P.rf / 2;
     for (int r = r_begin; r < half; ++r) {
         pair_sbox_full<T>(s, P.rc_full + r * T);
-        pair_apply_lu<T>(s, (r == half - 1) ? P.lu_pre : P.lu);
+        pair_apply_lu<T>(s, (r == half - 1) ? P.lu_pre29 : P.lu29);
     }
     fr_t s0 = fr_zero<PF>();
     if (!s.isY) s0 = s.ld(0);
     for (int b = 0; b < P.rp / 4; ++b) {
-        const fr_t* sp = P.sparse + (size_t)(4 * b) * W;
-        const fr_t* g = P.gamma + (size_t)b * 6;
+        const uint32_t* sp = c29(P.sparse29, (size_t)(4 * b) * W);
+        const uint32_t* g = c29(P.gamma29, (size_t)b * 6);
         if (!s.isY) {
             // ---- X: the S-box chain ------------------------------------------------------------------------
             fr_t keep[NXD];
 #pragma unroll
-            for (int j = 0; j < NXD; ++j) keep[j] = s.ld(1 + j);      // their slots become Y's mailboxes for this block
+            for (int j = 0; j < NXD; ++j) keep[j] = s.ld(1 + j);                  // their slots become Y's mailboxes for this block
             __syncthreads();                                           // S: mailboxes may be written from here on
-            fr_t x0, x1, x2, x3;
-#define STARK_PAIR_ROUND(q, XQ)                                                                       \
+            // x_0..x_3 live in their LDS mailboxes (this wave reads back its own writes in order); keeping them in
+            // registers across the four rounds costs 36 VGPRs and pushes the allocator into scratch.
+#define STARK_PAIR_ROUND(q)                                                                           \
             {                                                                                         \
-                XQ = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                             \
-                s.sto(Cfg::xslot(q), XQ);                                                             \
-                fr_wide acc; fr_wide_zero(acc);                                                       \
-                fr_wide_mac_f<PF>(acc, sp[q * W], XQ);                                                \
-                if (q > 0) fr_wide_mac_f<PF>(acc, g[q * (q - 1) / 2 + 0], x0);                         \
-                if (q > 1) fr_wide_mac_f<PF>(acc, g[q * (q - 1) / 2 + 1], x1);                         \
-                if (q > 2) fr_wide_mac_f<PF>(acc, g[q * (q - 1) / 2 + 2], x2);                         \
-                _Pragma("unroll") for (int j = 0; j < NXD; ++j) fr_wide_mac_f<PF>(acc, sp[q * W + 1 + j], keep[j]); \
-                const fr_t part = fr_wide_reduce<PF>(acc);                                            \
+                const fr_t xq = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                  \
+                s.sto(Cfg::xslot(q), xq);                                                             \
+                fr_wide29 acc; fr_wide29_zero(acc);                                                   \
+                fr_wide29_mac(acc, c29(sp, q * W), fr29_unpack(xq));                                  \
+                if (q > 0) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 0), fr29_unpack(s.ld(Cfg::xslot(0)))); \
+                if (q > 1) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 1), fr29_unpack(s.ld(Cfg::xslot(1)))); \
+                if (q > 2) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 2), fr29_unpack(s.ld(Cfg::xslot(2)))); \
+                _Pragma("unroll") for (int j = 0; j < NXD; ++j) {                                     \
+                    if (1 + q + j == 6) fr_wide29_norm(acc);           /* carry pass after 6 terms */  \
+                    fr_wide29_mac(acc, c29(sp, q * W + 1 + j), fr29_unpack(keep[j]));                 \
+                }                                                                                     \
+                const fr_t part = fr_wide29_reduce<PF>(acc);                                          \
                 __syncthreads();                                       /* barrier_q: Dy_q is posted */ \
                 s0 = fr_add<PF>(part, s.ld(Cfg::dslot(q)));                                           \
             }
-            STARK_PAIR_ROUND(0, x0) STARK_PAIR_ROUND(1, x1) STARK_PAIR_ROUND(2, x2) STARK_PAIR_ROUND(3, x3)
+            STARK_PAIR_ROUND(0) STARK_PAIR_ROUND(1) STARK_PAIR_ROUND(2) STARK_PAIR_ROUND(3)
 #undef STARK_PAIR_ROUND
             // ---- X: lanes 1..NXU up to date -------------------------------------------------------------------
+            const fr29_t x0 = fr29_unpack(s.ld(Cfg::xslot(0))), x1 = fr29_unpack(s.ld(Cfg::xslot(1))), x2 = fr29_unpack(s.ld(Cfg::xslot(2))), x3 = fr29_unpack(s.ld(Cfg::xslot(3)));
 #pragma unroll
             for (int j = 1; j <= NXD; ++j) s.sto(j, pair_lane_update<T>(sp, j, keep[j - 1], x0, x1, x2, x3));
+#pragma unroll 1
             for (int j = NXD + 1; j <= NXU; ++j) s.sto(j, pair_lane_update<T>(sp, j, s.ld(j), x0, x1, x2, x3));
         } else {
             // ---- Y: three quarters of every round's dot product, from the block-start state ----------------------
             __syncthreads();                                           // S
             for (int q = 0; q < 4; ++q) {
-                fr_wide acc; fr_wide_zero(acc);
-                for (int j = NXD + 1; j < T; ++j) fr_wide_mac_f<PF>(acc, sp[q * W + j], s.ld(j));
-                const fr_t dy = fr_wide_reduce<PF>(acc);
+                DotAcc acc; acc.init();
+#pragma unroll 1
+                for (int j = NXD + 1; j < T; ++j) acc.mac(c29(sp, q * W + j), s.ld(j));
+                const fr_t dy = acc.finish();
                 s.sto(Cfg::dslot(q), dy);
                 __syncthreads();                                       // barrier_q
             }
             // ---- Y: lanes NXU+1..T-1 up to date (x_0..x_3 were posted before barrier_0..3) ---------------------------
-            const fr_t x0 = s.ld(Cfg::xslot(0)), x1 = s.ld(Cfg::xslot(1)), x2 = s.ld(Cfg::xslot(2)), x3 = s.ld(Cfg::xslot(3));
+            const fr29_t x0 = fr29_unpack(s.ld(Cfg::xslot(0))), x1 = fr29_unpack(s.ld(Cfg::xslot(1))), x2 = fr29_unpack(s.ld(Cfg::xslot(2))), x3 = fr29_unpack(s.ld(Cfg::xslot(3)));
+#pragma unroll 1
             for (int j = NXU + 1; j < T; ++j) s.sto(j, pair_lane_update<T>(sp, j, s.ld(j), x0, x1, x2, x3));
         }
         __syncthreads();                                               // E: lanes 1..T-1 consistent, mailboxes free
@@ -154,21 +164,23 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
         pair_sbox_full<T>(s, P.rc_full + r * T);
         if (only0 && r == P.rf - 1) {                       // squeeze: row 0 only, split over the two waves
             const int j0 = s.isY ? Cfg::NX : 0, j1 = s.isY ? T : Cfg::NX;
-            fr_wide acc; fr_wide_zero(acc);
-            for (int j = j0; j < j1; ++j) fr_wide_mac_f<PF>(acc, P.row0[j], s.ld(j));
-            s.sto(T + (s.isY ? 1 : 0), fr_wide_reduce<PF>(acc));     // two of the extra slots: not part of the state
+            DotAcc acc; acc.init();
+#pragma unroll 1
+            for (int j = j0; j < j1; ++j) acc.mac(c29(P.row0_29, j), s.ld(j));
+            s.sto(T + (s.isY ? 1 : 0), acc.finish());                // two of the extra slots: not part of the state
             __syncthreads();
             fr_t out = fr_add<PF>(s.ld(T + 0), s.ld(T + 1));
             __syncthreads();                                 // the slots are reused by the next permutation
             return out;
         }
-        pair_apply_lu<T>(s, P.lu);
+        pair_apply_lu<T>(s, P.lu29);
     }
     return s.ld(0);
 }
 
 __device__ __forceinline__ PairState pair_setup(uint4* lds) {
-    PairState s; s.st = lds; s.lane = threadIdx.x & 63; s.isY = threadIdx.x >= 64;
+    PairState s; s.st = lds; s.lane = threadIdx.x & 63;
+    s.isY = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;      // wave-uniform by construction: tell the compiler (scalar branches, scalar constant loads)
     return s;
 }
 
@@ -184,10 +196,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k
     const fr_t x4 = fr_pow5<PF>(fr_add<PF>(ldg(f + ii), P.rc_full[4]));
     const fr_t x5 = fr_pow5<PF>(fr_add<PF>(f_next ? ldg(f_next + ii / m) : fr_zero<PF>(), P.rc_full[5]));
     const int j0 = s.isY ? PairCfg<17>::NX : 0, j1 = s.isY ? 17 : PairCfg<17>::NX;
+    const uint32_t* m45 = reinterpret_cast<const uint32_t*>(leafc + 51);   // columns 4 and 5 of M in radix 2^29 (17 + 17 entries)
+    const fr29_t x4u = fr29_unpack(x4), x5u = fr29_unpack(x5);
     for (int j = j0; j < j1; ++j) {
-        fr_wide w; fr_wide_zero(w);
-        fr_wide_mac_f<PF>(w, leafc[17 + j], x4); fr_wide_mac_f<PF>(w, leafc[34 + j], x5);
-        s.sto(j, fr_add<PF>(leafc[j], fr_wide_reduce<PF>(w)));
+        fr_wide29 w; fr_wide29_zero(w);
+        fr_wide29_mac(w, c29(m45, j), x4u); fr_wide29_mac(w, c29(m45, 17 + j), x5u);
+        s.sto(j, fr_add<PF>(leafc[j], fr_wide29_reduce<PF>(w)));
     }
     __syncthreads();
     fr_t out = pair_permute<17>(s, P, true, 1);

@@ -13,6 +13,8 @@ struct PoseidonDev {           // device pointers to kernel-form constants (see 
     const fr_t* mds;           // t*t  reference form
     const fr_t* mds_pre;       // t*t  dense B_1*M
     const fr_t* gamma;         // (rp/4)*6  cross terms of the 4-round partial blocks
+    // the same multiplier tables in radix 2^29, R' = 2^261 domain, 9 words per entry (fr29.hpp): what the dot products read
+    const uint32_t* lu29; const uint32_t* lu_pre29; const uint32_t* row0_29; const uint32_t* sparse29; const uint32_t* gamma29;
 };
 
 }  // namespace stark
