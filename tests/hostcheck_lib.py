@@ -28,6 +28,9 @@ class HostCheck:
     def wide_dot(self, a, b):
         a, b = A(a), A(b); out = np.zeros(4, np.uint64); self.l.hc_wide_dot(P(a), P(b), C.c_size_t(a.shape[0]), P(out)); return out
 
+    def wide_dot32(self, a, b):
+        a, b = A(a), A(b); out = np.zeros(4, np.uint64); assert self.l.hc_wide_dot32(P(a), P(b), C.c_size_t(a.shape[0]), P(out)) == 0; return out
+
     def blake3(self, data: bytes):
         out = (C.c_uint8 * 32)(); buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
         self.l.hc_blake3(buf, C.c_size_t(len(data)), out); return bytes(out)

@@ -114,9 +114,11 @@ def test_hash_stream_body(oracle, hostcheck):
     hostcheck.params_free(h17); hostcheck.params_free(hseed)
 
 
-@pytest.mark.parametrize("n", [1, 2, 17, 24, 25, 27, 48, 129])
+@pytest.mark.parametrize("n", [1, 2, 6, 7, 12, 13, 17, 24, 25, 27, 48, 59, 60, 61, 120, 129])
 def test_wide_dot_worst_case_and_random(oracle, hostcheck, n):
-    """Sums of products with ONE Montgomery reduction per chunk: worst case (all operands r-1) and random."""
+    """Sums of products with ONE Montgomery reduction per chunk (radix-2^29 columns, constants in the 2^261 domain:
+    carry pass every 6 terms, chunks of 60 — csrc/fr29.hpp): worst case (all operands r-1) and random, across every
+    chunk boundary; the radix-2^32 accumulator of the cooperative kernels must agree where it applies (<= 24 terms)."""
     p = pyref.P_PALLAS
     top = oracle.from_int(p - 1)
     a = np.tile(top, (n, 1)); b = np.tile(top, (n, 1))
@@ -124,3 +126,6 @@ def test_wide_dot_worst_case_and_random(oracle, hostcheck, n):
     a = oracle.synth_column(17, 0, 0, n); b = oracle.synth_column(17, 1, 0, n)
     want = sum(oracle.to_int(a[i]) * oracle.to_int(b[i]) for i in range(n)) % p
     assert oracle.to_int(hostcheck.wide_dot(a, b)) == want
+    if n <= 24:
+        assert oracle.to_int(hostcheck.wide_dot32(a, b)) == want
+        assert oracle.to_int(hostcheck.wide_dot32(np.tile(top, (n, 1)), np.tile(top, (n, 1)))) == (n * (p - 1) * (p - 1)) % p
