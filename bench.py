@@ -54,6 +54,8 @@ def main():
     ndev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:

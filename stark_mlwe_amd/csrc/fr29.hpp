@@ -13,9 +13,10 @@
 // divides by R', so  sum_i (c_i R')(x_i R) / R' = (sum_i c_i x_i) R  — the result is again in the R domain.
 // r = 1 (mod 2^29) in both fields, so the quotient digit is m = -t mod 2^29 with no multiply.
 //
-// Bounds (operands reduced, < r < 2^255): a column gains < 9 * 2^58 per term; normalise (carry pass) after at
-// most 7 terms, reduce after at most 6 terms since the last normalisation (the reduction adds < 9 * 2^58 more
-// per column).  For a sum of K <= 64 terms the Montgomery step leaves < (K/128 + 1) r < 2r: ONE conditional
+// Bounds (operands reduced, < r < 2^255, so limb 8 is below 2^23): a column gains < 8 * 2^58 per term (column 7:
+// eight full products; column 8 has nine but two of them involve a top limb), the reduction adds < 6 * 2^58 per
+// column (five non-zero limbs of r besides limb 0, plus the carry): at most 7 terms between carry passes, and
+// at most 7 terms since the last pass when the reduction starts (7*8 + 6 = 62 < 64).  For a sum of K <= 64 terms the Montgomery step leaves < (K/128 + 1) r < 2r: ONE conditional
 // subtraction.  Portable C++ (host build for the CPU checks; on the device the products compile to
 // v_mad_u64_u32 with the 64-bit add folded in).
 #pragma once
@@ -31,6 +32,13 @@ template <class F> constexpr uint32_t fr_p29(int i) {      // limb i of the modu
     const int lo = 29 * i, w = lo >> 5, s = lo & 31;
     const uint64_t x = (w < 8 ? (uint64_t)F::P(w) : 0ull) | (w + 1 < 8 ? ((uint64_t)F::P(w + 1) << 32) : 0ull);
     return (uint32_t)(x >> s) & FR_M29;
+}
+
+// Terms a column can take between carry passes (and before the reduction): 8 * 2^58 per term, (nz + 1) * 2^58 from the reduction.
+template <class F> constexpr int fr29_max_terms() {
+    int nz = 0;
+    for (int j = 1; j < 9; ++j) nz += fr_p29<F>(j) != 0 ? 1 : 0;
+    return (64 - (nz + 1)) / 8;
 }
 
 FR_HD fr29_t fr29_unpack(const fr_t& x) {

@@ -35,13 +35,13 @@ struct ArrayState {
 };
 
 // Dot product  sum_i c_i * x_i  with ONE Montgomery reduction: constants as nine 29-bit limbs in the 2^261
-// domain, carry-free column sums (fr29.hpp).  A carry pass every 6 terms keeps the 64-bit columns in range;
+// domain, carry-free column sums (fr29.hpp).  A carry pass every 7 terms (Pallas) keeps the 64-bit columns in range;
 // rows longer than 60 terms (t = 65, 129) are reduced in chunks.
 struct DotAcc {
     fr_wide29 w; fr_t sum; int since, total; bool have_sum;
     FR_HD void init() { fr_wide29_zero(w); since = 0; total = 0; have_sum = false; }
     FR_HD void mac(const uint32_t* __restrict__ c29, const fr_t& x) {
-        if (since == 6) { fr_wide29_norm(w); since = 0; }
+        if (since == fr29_max_terms<PF>()) { fr_wide29_norm(w); since = 0; }
         fr_wide29_mac(w, c29, fr29_unpack(x)); ++since;
         if (++total == 60) { fr_t r = fr_wide29_reduce<PF>(w); sum = have_sum ? fr_add<PF>(sum, r) : r; have_sum = true; fr_wide29_zero(w); since = 0; total = 0; }
     }

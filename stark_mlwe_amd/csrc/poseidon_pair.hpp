@@ -28,12 +28,15 @@
 namespace stark {
 
 template <int T> struct PairCfg {
-    static constexpr int NXD = (T - 1) / 4;            // X's share of the lanes in the per-round dot products: lanes 1..NXD
+    static constexpr int NXD = T == 17 ? 3 : 2;        // X's share of the lanes in the per-round dot products: lanes 1..NXD (X's sums stay
+                                                       // <= 7 terms: no carry pass in the S-box chain; Y takes the other lanes)
     static constexpr int NXU = (T - 1) / 2;            // X updates lanes 1..NXU, Y lanes NXU+1..T-1
     static constexpr int NX = (T - 1) / 2;             // full rounds: X owns elements 0..NX-1 (S-box, absorb), Y the rest
-    static constexpr int EXTRA = 3 + (NXD < 4 ? 4 - NXD : 0);   // slots beyond the state: x mailboxes 1..3 + the Dy mailboxes that cannot alias
+    static constexpr int EXTRA = 3;                    // slots beyond the state: x mailboxes 1..3
     __host__ __device__ static constexpr int xslot(int p) { return p == 0 ? 0 : T + (p - 1); }
-    __host__ __device__ static constexpr int dslot(int q) { return q < NXD ? 1 + q : T + 3 + (q - NXD); }
+    // Dy mailboxes alias the state slots X preloaded (1..NXD), reused round-robin: Dy_q is read before barrier_{q+1},
+    // Dy_{q+NXD} is written after barrier_{q+NXD-1} >= barrier_{q+1}
+    __host__ __device__ static constexpr int dslot(int q) { return 1 + (q % NXD); }
     __host__ __device__ static constexpr size_t lds_bytes() { return (size_t)(T + EXTRA) * 2 * 64 * 16; }
 };
 static inline size_t pair_lds_bytes(int t) { return t == 17 ? PairCfg<17>::lds_bytes() : PairCfg<9>::lds_bytes(); }
@@ -117,6 +120,7 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
             // registers across the four rounds costs 36 VGPRs and pushes the allocator into scratch.
 #define STARK_PAIR_ROUND(q)                                                                           \
             {                                                                                         \
+                __builtin_amdgcn_sched_barrier(0);                     /* keep the rounds apart: less register pressure */ \
                 const fr_t xq = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                  \
                 s.sto(Cfg::xslot(q), xq);                                                             \
                 fr_wide29 acc; fr_wide29_zero(acc);                                                   \
@@ -124,10 +128,8 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
                 if (q > 0) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 0), fr29_unpack(s.ld(Cfg::xslot(0)))); \
                 if (q > 1) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 1), fr29_unpack(s.ld(Cfg::xslot(1)))); \
                 if (q > 2) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 2), fr29_unpack(s.ld(Cfg::xslot(2)))); \
-                _Pragma("unroll") for (int j = 0; j < NXD; ++j) {                                     \
-                    if (1 + q + j == 6) fr_wide29_norm(acc);           /* carry pass after 6 terms */  \
-                    fr_wide29_mac(acc, c29(sp, q * W + 1 + j), fr29_unpack(keep[j]));                 \
-                }                                                                                     \
+                static_assert(1 + 3 + NXD <= fr29_max_terms<PF>(), "terms between carry passes (fr29.hpp)");   \
+                _Pragma("unroll") for (int j = 0; j < NXD; ++j) fr_wide29_mac(acc, c29(sp, q * W + 1 + j), fr29_unpack(keep[j])); \
                 const fr_t part = fr_wide29_reduce<PF>(acc);                                          \
                 __syncthreads();                                       /* barrier_q: Dy_q is posted */ \
                 s0 = fr_add<PF>(part, s.ld(Cfg::dslot(q)));                                           \
@@ -137,7 +139,7 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
             // ---- X: lanes 1..NXU up to date -------------------------------------------------------------------
             const fr29_t x0 = fr29_unpack(s.ld(Cfg::xslot(0))), x1 = fr29_unpack(s.ld(Cfg::xslot(1))), x2 = fr29_unpack(s.ld(Cfg::xslot(2))), x3 = fr29_unpack(s.ld(Cfg::xslot(3)));
 #pragma unroll
-            for (int j = 1; j <= NXD; ++j) s.sto(j, pair_lane_update<T>(sp, j, keep[j - 1], x0, x1, x2, x3));
+            for (int j = 1; j <= NXD; ++j) { __builtin_amdgcn_sched_barrier(0); s.sto(j, pair_lane_update<T>(sp, j, keep[j - 1], x0, x1, x2, x3)); }
 #pragma unroll 1
             for (int j = NXD + 1; j <= NXU; ++j) s.sto(j, pair_lane_update<T>(sp, j, s.ld(j), x0, x1, x2, x3));
         } else {

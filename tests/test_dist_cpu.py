@@ -98,7 +98,7 @@ class CpuStandIn:
 
 def _worker(rank, world, port, log_n, log_rows, inverse, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from stark_mlwe_amd import dist as sd
@@ -146,7 +146,7 @@ def test_six_step_ntt_and_sharded_merkle_world2(log_n, log_rows, inverse):
 
 def _prove_worker(rank, world, port, log_n0, schedule, r, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from stark_mlwe_amd import dist as sd

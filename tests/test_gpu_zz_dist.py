@@ -1,6 +1,7 @@
 """Two ranks sharing ONE MI355X (gloo for the exchange, staged through host memory): the product kernels in
 a real 2-way decomposition — non-zero global column offsets in the six-step NTT, global DS positions in
-the sharded Merkle tree — against the oracle.  The 8-GPU RCCL run itself is the driver's."""
+the sharded Merkle tree — against the oracle.  The 8-GPU RCCL run itself is the driver's.
+(File name: sorts after test_gpu_parity.py so the single-process parity suite reports first.)"""
 import os
 import sys
 
@@ -14,9 +15,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _rendezvous_env(port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # loopback only: never resolve the box's hostname
+
+
+def _collect(procs, q, n, what, limit_s=420):
+    """Results of n workers; a worker that died or hangs fails the test with a message instead of stalling the run."""
+    import queue, time
+    res, t0 = [], time.time()
+    while len(res) < n:
+        try:
+            res.append(q.get(timeout=20))
+        except queue.Empty:
+            sys.__stderr__.write(f"[{what}: waiting {int(time.time() - t0)} s]\n"); sys.__stderr__.flush()
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > limit_s:
+                for p in procs:
+                    if p.is_alive(): p.terminate()
+                pytest.fail(f"{what}: workers did not report (exit codes {[p.exitcode for p in procs]}, {int(time.time() - t0)} s)")
+    for p in procs: p.join(60)
+    return res
+
+
 def _worker(rank, world, port, log_n, log_rows, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    _rendezvous_env(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle_lib
@@ -40,6 +64,9 @@ def _worker(rank, world, port, log_n, log_rows, q):
         ok_m = bool((root.cpu().numpy().view(np.uint64) == o.merkle_build(16, 9, leaves).root()).all())
         ctx.close()
         q.put((rank, ok_t, ok_n, ok_m))
+    except Exception as ex:      # noqa: BLE001 — report instead of leaving the parent waiting
+        import traceback
+        q.put(("error", repr(ex), traceback.format_exc()[-1500:]))
     finally:
         dist.destroy_process_group()
 
@@ -51,14 +78,13 @@ def test_two_ranks_share_one_gpu(log_n, log_rows):
     port = 29700 + (os.getpid() % 1000) + log_n
     procs = [ctx.Process(target=_worker, args=(r, 2, port, log_n, log_rows, q)) for r in range(2)]
     for p in procs: p.start()
-    res = [q.get(timeout=500) for _ in procs]
-    for p in procs: p.join(120)
+    res = _collect(procs, q, 2, "six-step + sharded merkle")
     assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
 
 
 def _prove_worker(rank, world, port, log_n0, schedule, r, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    _rendezvous_env(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle_lib
@@ -77,6 +103,9 @@ def _prove_worker(rank, world, port, log_n0, schedule, r, q):
             ref = o.deep_fri_prove(*cols, n0, schedule, r, 0xDEEFBAAD); ok_oracle = ref.bytes() == proof; ref.free()
         ctx.close()
         q.put((rank, proof == single, est == est1, ok_oracle, o.deep_fri_verify(proof, schedule, r, 0xDEEFBAAD)))
+    except Exception as ex:      # noqa: BLE001 — report instead of leaving the parent waiting
+        import traceback
+        q.put(("error", repr(ex), traceback.format_exc()[-1500:]))
     finally:
         dist.destroy_process_group()
 
@@ -89,14 +118,13 @@ def test_sharded_prove_two_ranks_one_gpu(log_n0, schedule, r):
     port = 29900 + (os.getpid() % 1000) + log_n0
     procs = [ctx.Process(target=_prove_worker, args=(r_, 2, port, log_n0, schedule, r, q)) for r_ in range(2)]
     for p in procs: p.start()
-    res = [q.get(timeout=900) for _ in procs]
-    for p in procs: p.join(120)
+    res = _collect(procs, q, 2, "sharded prove")
     want_oracle = True if log_n0 <= 12 else None
     assert sorted(res) == [(0, True, True, want_oracle, 1), (1, True, True, want_oracle, 1)], res
 
 
 def _rccl_worker(port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    _rendezvous_env(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -112,6 +140,9 @@ def _rccl_worker(port, q):
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier(); torch.cuda.synchronize()
         q.put((ok_a2a, ok_ag, ok_ar, ok_g, float(t.item())))
+    except Exception as ex:      # noqa: BLE001 — report instead of leaving the parent waiting
+        import traceback
+        q.put(("error", repr(ex), traceback.format_exc()[-1500:]))
     finally:
         dist.destroy_process_group()
 
@@ -123,6 +154,5 @@ def test_rccl_collectives_accept_our_tensors():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(30900 + os.getpid() % 1000, q))
     p.start()
-    res = q.get(timeout=300)
-    p.join(60)
+    res = _collect([p], q, 1, "rccl one-rank", limit_s=240)[0]
     assert res == (True, True, True, True, 1.5), res
