@@ -9,9 +9,9 @@
 //   * full rounds: S-boxes in parallel (3 product latencies), then the dense MDS with the row split
 //     three ways over lanes (i, q), q = 0..2 (51 lanes): each sums ~6 terms of row i in a wide
 //     accumulator, the three partials are added across lanes; the MDS matrix sits in LDS;
-//   * partial rounds (sparse form): while lane 0 computes x^2 of the S-box the other lanes already form
-//     u_j*s_j; after the S-box one more parallel product gives a*s0 and w_j*s0, then a shuffle tree
-//     sums the 17 partial products: 4 product latencies + one reduction per round instead of 36 products.
+//   * partial rounds, in blocks of 4: the dot products of all four rounds are taken at once against the block-start
+//     lanes (64 products in one slot + a butterfly sum), and a round is three product latencies: x^2 on one lane while
+//     the others form c*x, then x^4, then (c*x)*x^4 = c*x^5 for c in {w_j, a, gamma} — x^5 itself is never formed.
 // Same field values as the reference's dense rounds (the kernel-form constants of host_util.hpp).
 #pragma once
 #include "fr.hpp"
@@ -76,24 +76,44 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
         __builtin_amdgcn_wave_barrier();
     };
     for (int r = 0; r < half; ++r) full_round(r, r == half - 1 ? L.mpre : L.mds);
-    // partial rounds: constants of round r for this lane: lane 0 -> (a, rc_partial), lane j -> (u_j, w_j)
-    for (int r = 0; r < P.rp; ++r) {
-        const fr_t* sp = P.sparse + (size_t)r * w;
-        const fr_t cu = elem ? ldg(sp + lane) : fr_zero<PF>();                       // a (lane 0) / u_j
-        const fr_t cw = (elem && lane > 0) ? ldg(sp + T - 1 + lane) : fr_zero<PF>();  // w_j
-        // slot 1: lane 0: x^2 with x = s0 + rc ; lanes j: u_j * s_j
-        fr_t x = fr_add<PF>(s, ldg(P.rc_partial + r));
-        fr_t m1 = fr_mul<PF>(lane == 0 ? x : cu, lane == 0 ? x : s);
-        // slots 2,3 (lane 0 only; the other lanes run along): x^4, x^5
-        fr_t x4 = fr_mul<PF>(m1, m1);
-        fr_t x5 = fr_mul<PF>(x, x4);
-        const fr_t s0n = shfl_fr(x5, 0);                                             // s0 after the S-box, to every lane
-        // slot 4: lane 0: a*s0 ; lanes j: w_j*s0
-        fr_t m4 = fr_mul<PF>(lane == 0 ? cu : cw, s0n);
-        fr_t term = lane == 0 ? m4 : (elem ? m1 : fr_zero<PF>());                    // summands of s0' = a*s0 + sum u_j s_j
-        for (int d = 16; d >= 1; d >>= 1) { fr_t o = shfl_down_fr(term, d); if (lane + d < 32) term = fr_add<PF>(term, o); }
-        if (lane == 0) s = term; else if (elem) s = fr_add<PF>(s, m4);
+    // Partial rounds in blocks of 4 (the algebra of permute_core, poseidon_dev.hpp), three product latencies per round:
+    //   block start : all 4*(T-1) products u_{q,j}*s_j at once (lane (q, j)), butterfly-summed per round -> D_q, parked
+    //                 in the "accumulator" lanes 32+q of the state register;
+    //   round q     : x = s0 + c.  slot 1: lane 48 squares x while lane j forms w_{q,j}*x and accumulator lane 32+q'
+    //                 forms a_q*x (q' = q) or gamma_{q',q}*x (q' > q);  slot 2: x^4 on every lane;  slot 3: (slot 1) * x^4,
+    //                 i.e. w x^5 / a x^5 / gamma x^5 without ever forming x^5 itself; one lane-wise add brings the lanes
+    //                 s_j and the accumulators up to date, and accumulator lane 32+q now holds the next s0.
+    constexpr int RATE = T - 1, LOG_RATE = RATE == 16 ? 4 : 3;
+    static_assert(RATE == 16 || RATE == 8, "cooperative form: t = 17 or t = 9");
+    fr_t s0v = shfl_fr(s, 0);                                                         // s0, replicated on every lane
+    const bool acc_lane = lane >= 32 && lane < 36, sq_lane = lane == 48;
+    for (int b = 0; b < P.rp / 4; ++b) {
+        const fr_t* sp = P.sparse + (size_t)(4 * b) * w;
+        {   // D_q = sum_j u_{q,j} s_j from the block-start lanes
+            const int dq = lane >> LOG_RATE, dj = 1 + (lane & (RATE - 1));
+            const fr_t sj = shfl_fr(s, dj);
+            fr_t v = dq < 4 ? fr_mul<PF>(ldg(sp + dq * w + dj), sj) : fr_zero<PF>();
+#pragma unroll
+            for (int d = RATE / 2; d >= 1; d >>= 1) v = fr_add<PF>(v, shfl_xor_fr(v, d));
+            const fr_t dv = shfl_fr(v, (lane - 32) << LOG_RATE);                      // lanes 32..35 fetch D_0..D_3 (other lanes: unused)
+            if (acc_lane) s = dv;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const fr_t* spq = sp + q * w;
+            fr_t cst = fr_zero<PF>();
+            if (lane >= 1 && lane < T) cst = ldg(spq + T - 1 + lane);                 // w_{q,lane}
+            else if (acc_lane) { const int qq = lane - 32; if (qq == q) cst = ldg(spq); else if (qq > q) cst = ldg(P.gamma + b * 6 + qq * (qq - 1) / 2 + q); }
+            const fr_t x = fr_add<PF>(s0v, ldg(P.rc_partial + 4 * b + q));
+            const fr_t m1 = fr_mul<PF>(sq_lane ? x : cst, x);                         // slot 1
+            const fr_t x2 = shfl_fr(m1, 48);
+            const fr_t x4 = fr_mul<PF>(x2, x2);                                       // slot 2
+            const fr_t m3 = fr_mul<PF>(m1, x4);                                       // slot 3 (zero where cst is zero)
+            s = fr_add<PF>(s, m3);
+            s0v = shfl_fr(s, 32 + q);
+        }
     }
+    if (lane == 0) s = s0v;
     for (int r = half; r < P.rf; ++r) full_round(r, L.mds);
     return s;
 }
