@@ -153,7 +153,8 @@ static int32_t ctx_leaf_init(stark_ctx* ctx, fr_t** out) {
             for (int j = 0; j < 17; ++j) if (j != 4 && j != 5) k = host::h_add(k, host::h_mul(c.mds[(size_t)i * 17 + j], x[j]));
             blob[17 + i] = k; blob[34 + i] = c.mds[(size_t)i * 17 + 4]; blob[51 + i] = c.mds[(size_t)i * 17 + 5];
             uint32_t* m45 = reinterpret_cast<uint32_t*>(&blob[68]);
-            fr29_const_from<PallasFr>(c.mds[(size_t)i * 17 + 4], m45 + 9 * i); fr29_const_from<PallasFr>(c.mds[(size_t)i * 17 + 5], m45 + 9 * (17 + i));
+            const fr_t k20 = fr_from_u64<PallasFr>(1ull << FR29_SBOX_SHIFT);     // the S-box outputs x4, x5 arrive divided by 2^20 (fr_pow5_r29)
+            fr29_const_from<PallasFr>(host::h_mul(c.mds[(size_t)i * 17 + 4], k20), m45 + 9 * i); fr29_const_from<PallasFr>(host::h_mul(c.mds[(size_t)i * 17 + 5], k20), m45 + 9 * (17 + i));
         }
         STARK_HIP(ctx, hipMalloc((void**)&ctx->leaf_init, sizeof(blob)));
         STARK_HIP(ctx, hipMemcpyAsync(ctx->leaf_init, blob, sizeof(blob), hipMemcpyHostToDevice, ctx->stream));

@@ -80,8 +80,9 @@ FR_HD void fr_wide29_norm(fr_wide29& w) {
 #pragma unroll
     for (int k = 0; k < 17; ++k) { w.c[k + 1] += w.c[k] >> 29; w.c[k] &= FR_M29; }
 }
-// Montgomery reduction by R' = 2^261 and return to eight 32-bit limbs, fully reduced.
-template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
+// Montgomery step: divides the column sums by R' = 2^261; l[0..8] = limbs of the quotient (l[8] keeps every bit
+// above 2^232).  For a sum of K products of operands below 2r the quotient is below (K/32 + 1) r.
+template <class F> FR_HD void fr_wide29_mont(fr_wide29& w, uint32_t* l) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const uint64_t t = w.c[k];
@@ -91,10 +92,12 @@ template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
         for (int j = 1; j < 9; ++j)
             if (fr_p29<F>(j) != 0) w.c[k + j] += (uint64_t)m * fr_p29<F>(j);
     }
-    // columns 9..17 hold the quotient: carry-propagate into 29-bit limbs, then regroup into 32-bit words
-    uint32_t l[9]; uint64_t carry = 0;
+    uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) { const uint64_t v = w.c[9 + i] + carry; l[i] = i < 8 ? ((uint32_t)v & FR_M29) : (uint32_t)v; carry = v >> 29; }
+}
+// nine 29-bit limbs (value < 2r) -> eight 32-bit limbs, fully reduced
+template <class F> FR_HD fr_t fr29_pack_reduce(const uint32_t* l) {
     uint32_t t[9];
 #pragma unroll
     for (int wd = 0; wd < 8; ++wd) {
@@ -110,6 +113,43 @@ template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) z.v[i] = t[i];
     return z;
+}
+// Montgomery reduction by R' = 2^261 and return to eight 32-bit limbs, fully reduced.
+template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
+    uint32_t l[9]; fr_wide29_mont<F>(w, l);
+    return fr29_pack_reduce<F>(l);
+}
+
+// ---- the S-box in radix 2^29 ---------------------------------------------------------------------------------
+// x^5 = x * (x^2)^2 with two SQUARINGS: in radix 2^29 a doubled limb still fits the 32-bit multiplier operand, so a
+// square is 36 cross products (against 2*l_j) + 9 squares = 45 MACs instead of 81 (in radix 2^32 doubling a limb
+// overflows the operand, and doubling column sums costs what it saves).  Values stay as nine limbs, below 1.01 r,
+// between the three steps; each step divides by R' = 2^261 while the operands carry R = 2^256, so the result is
+//     fr_pow5_r29(x R) = x^5 R / 2^20      (three times a factor 2^5, compounded: 2^-5, 2^-15, 2^-20)
+// and every constant that multiplies an S-box output is stored pre-multiplied by 2^20 (host_util.hpp to_radix29).
+template <class F> FR_HD fr29_t fr29_sqr_mont(const fr29_t& a) {
+    fr_wide29 w; fr_wide29_zero(w);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        w.c[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; ++j) w.c[i + j] += (uint64_t)a.l[i] * (a.l[j] << 1);
+    }
+    fr29_t r; fr_wide29_mont<F>(w, r.l); return r;
+}
+template <class F> FR_HD fr29_t fr29_mul_mont(const fr29_t& a, const fr29_t& b) {
+    fr_wide29 w; fr_wide29_zero(w);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w.c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    fr29_t r; fr_wide29_mont<F>(w, r.l); return r;
+}
+constexpr int FR29_SBOX_SHIFT = 20;
+template <class F> FR_HD fr_t fr_pow5_r29(const fr_t& x) {
+    const fr29_t u = fr29_unpack(x);
+    const fr29_t x2 = fr29_sqr_mont<F>(u), x4 = fr29_sqr_mont<F>(x2), x5 = fr29_mul_mont<F>(u, x4);
+    return fr29_pack_reduce<F>(x5.l);
 }
 
 // Host side: the nine limbs of c * R' mod r for a constant given in the R domain (c * R mod r).

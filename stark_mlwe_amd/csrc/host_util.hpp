@@ -203,9 +203,11 @@ struct KernelConsts {
     std::vector<uint32_t> lu29, lu_pre29, row0_29, sparse29, gamma29;
     bool ok = false;
 };
-inline std::vector<uint32_t> to_radix29(const std::vector<fr_t>& v) {
+// scaled(i) == true: the entry multiplies an S-box output, which fr_pow5_r29 delivers as x^5 / 2^20 (fr29.hpp)
+template <class Pred> inline std::vector<uint32_t> to_radix29(const std::vector<fr_t>& v, Pred scaled) {
+    const fr_t k = fr_from_u64<PF>(1ull << FR29_SBOX_SHIFT);
     std::vector<uint32_t> o(v.size() * 9);
-    for (size_t i = 0; i < v.size(); ++i) fr29_const_from<PF>(v[i], &o[9 * i]);
+    for (size_t i = 0; i < v.size(); ++i) fr29_const_from<PF>(scaled(i) ? fr_mul<PF>(v[i], k) : v[i], &o[9 * i]);
     return o;
 }
 // Gauss-Jordan inverse of an n x n matrix (row-major); returns false when singular.
@@ -274,7 +276,13 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     if (!lu_pack(c.mds, t, k.lu)) return k;
     if (!lu_pack(cur, t, k.lu_pre)) return k;
     k.mds_pre = cur;
-    k.lu29 = to_radix29(k.lu); k.lu_pre29 = to_radix29(k.lu_pre); k.row0_29 = to_radix29(k.row0); k.sparse29 = to_radix29(k.sparse); k.gamma29 = to_radix29(k.gamma);
+    // radix-2^29 tables.  Scaled by 2^20: what meets an S-box output — U of every L*U (entries on/above the diagonal;
+    // L acts on U's result), row 0 of M, a_k and w_k of the sparse rounds (u_k meets the lanes, not an S-box output), gamma.
+    const auto upper = [t](size_t i) { return (int)(i % t) >= (int)(i / t); };
+    const auto all = [](size_t) { return true; };
+    const auto a_and_w = [t](size_t i) { const int c = (int)(i % (2 * t - 1)); return c == 0 || c >= t; };
+    k.lu29 = to_radix29(k.lu, upper); k.lu_pre29 = to_radix29(k.lu_pre, upper); k.row0_29 = to_radix29(k.row0, all);
+    k.sparse29 = to_radix29(k.sparse, a_and_w); k.gamma29 = to_radix29(k.gamma, all);
     k.ok = true;
     return k;
 }

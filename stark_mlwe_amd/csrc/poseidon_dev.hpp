@@ -72,7 +72,7 @@ template <class S> FR_HD void apply_lu(const S& s, const uint32_t* lu, int t) {
 template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, bool only0) {
     const int t = P.t, half = P.rf / 2;
     for (int r = 0; r < half; ++r) {
-        for (int j = 0; j < t; ++j) s.st(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));
+        for (int j = 0; j < t; ++j) s.st(j, fr_pow5_r29<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));   // x^5 / 2^20: the tables carry the 2^20
         apply_lu(s, (r == half - 1) ? P.lu_pre29 : P.lu29, t);
     }
     // Partial rounds in blocks of 4 (rp is a multiple of 4 for every supported width).  Within a block the
@@ -88,7 +88,7 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
         fr_t x0, x1, x2, x3;
 #define STARK_PARTIAL_ROUND(q, XQ)                                                              \
         {                                                                                       \
-            XQ = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                           \
+            XQ = fr_pow5_r29<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                       \
             DotAcc acc; acc.init();                                                             \
             acc.mac(c29(sp, q * w), XQ);                                                        \
             if (q > 0) acc.mac(c29(g, q * (q - 1) / 2 + 0), x0);                                 \
@@ -108,7 +108,7 @@ template <class S> FR_HD fr_t permute_core(const S& s, const PoseidonDev& P, boo
     }
     s.st(0, s0);
     for (int r = half; r < P.rf; ++r) {
-        for (int j = 0; j < t; ++j) s.st(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));
+        for (int j = 0; j < t; ++j) s.st(j, fr_pow5_r29<PF>(fr_add<PF>(s.ld(j), P.rc_full[r * t + j])));   // x^5 / 2^20: the tables carry the 2^20
         if (only0 && r == P.rf - 1) {
             DotAcc acc; acc.init();
             for (int j = 0; j < t; ++j) acc.mac(c29(P.row0_29, j), s.ld(j));

@@ -80,7 +80,7 @@ __device__ __forceinline__ void pair_apply_lu(const PairState& s, const uint32_t
 template <int T>
 __device__ __forceinline__ void pair_sbox_full(const PairState& s, const fr_t* rc) {
     const int j0 = s.isY ? PairCfg<T>::NX : 0, j1 = s.isY ? T : PairCfg<T>::NX;
-    for (int j = j0; j < j1; ++j) s.sto(j, fr_pow5<PF>(fr_add<PF>(s.ld(j), rc[j])));
+    for (int j = j0; j < j1; ++j) s.sto(j, fr_pow5_r29<PF>(fr_add<PF>(s.ld(j), rc[j])));
     __syncthreads();
 }
 
@@ -121,7 +121,7 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
 #define STARK_PAIR_ROUND(q)                                                                           \
             {                                                                                         \
                 __builtin_amdgcn_sched_barrier(0);                     /* keep the rounds apart: less register pressure */ \
-                const fr_t xq = fr_pow5<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));                  \
+                const fr_t xq = fr_pow5_r29<PF>(fr_add<PF>(s0, P.rc_partial[4 * b + q]));              \
                 s.sto(Cfg::xslot(q), xq);                                                             \
                 fr_wide29 acc; fr_wide29_zero(acc);                                                   \
                 fr_wide29_mac(acc, c29(sp, q * W), fr29_unpack(xq));                                  \
@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k
     // Round 0 in closed form: 15 of the 17 lanes of the transcript template are constants, so after ARK and
     // S-box the MDS output is  K_i + M[i][4]*x4 + M[i][5]*x5  with K precomputed on the host
     // (leafc = [K(17) | M[:,4](17) | M[:,5](17)]).  Both waves compute x4, x5; each fills its own lanes.
-    const fr_t x4 = fr_pow5<PF>(fr_add<PF>(ldg(f + ii), P.rc_full[4]));
-    const fr_t x5 = fr_pow5<PF>(fr_add<PF>(f_next ? ldg(f_next + ii / m) : fr_zero<PF>(), P.rc_full[5]));
+    const fr_t x4 = fr_pow5_r29<PF>(fr_add<PF>(ldg(f + ii), P.rc_full[4]));
+    const fr_t x5 = fr_pow5_r29<PF>(fr_add<PF>(f_next ? ldg(f_next + ii / m) : fr_zero<PF>(), P.rc_full[5]));
     const int j0 = s.isY ? PairCfg<17>::NX : 0, j1 = s.isY ? 17 : PairCfg<17>::NX;
     const uint32_t* m45 = reinterpret_cast<const uint32_t*>(leafc + 51);   // columns 4 and 5 of M in radix 2^29 (17 + 17 entries)
     const fr29_t x4u = fr29_unpack(x4), x5u = fr29_unpack(x5);
