@@ -34,6 +34,13 @@ __device__ __forceinline__ fr_t shfl_down_fr(const fr_t& x, int d) {
     for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], d, 64);
     return r;
 }
+// broadcast of one lane's element through SGPRs (v_readlane: no LDS-crossbar round trip); src is wave-uniform
+__device__ __forceinline__ fr_t bcast_fr(const fr_t& x, int src) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_readlane((int)x.v[i], src);
+    return r;
+}
 struct CoopLds { uint4* mds; uint4* mpre; uint4* x; };   // [T*T][2], [T*T][2], [T][2]
 __device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
     uint4 lo = base[2 * idx], hi = base[2 * idx + 1];
@@ -85,10 +92,20 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     //                 s_j and the accumulators up to date, and accumulator lane 32+q now holds the next s0.
     constexpr int RATE = T - 1, LOG_RATE = RATE == 16 ? 4 : 3;
     static_assert(RATE == 16 || RATE == 8, "cooperative form: t = 17 or t = 9");
-    fr_t s0v = shfl_fr(s, 0);                                                         // s0, replicated on every lane
+    fr_t s0v = bcast_fr(s, 0);                                                        // s0, replicated on every lane
     const bool acc_lane = lane >= 32 && lane < 36, sq_lane = lane == 48;
     for (int b = 0; b < P.rp / 4; ++b) {
         const fr_t* sp = P.sparse + (size_t)(4 * b) * w;
+        // this lane's multiplier for each of the four rounds, fetched up front (off the dependent chain)
+        fr_t cst[4], rcq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const fr_t* spq = sp + q * w;
+            cst[q] = fr_zero<PF>();
+            if (lane >= 1 && lane < T) cst[q] = ldg(spq + T - 1 + lane);              // w_{q,lane}
+            else if (acc_lane) { const int qq = lane - 32; if (qq == q) cst[q] = ldg(spq); else if (qq > q) cst[q] = ldg(P.gamma + b * 6 + qq * (qq - 1) / 2 + q); }
+            rcq[q] = ldg(P.rc_partial + 4 * b + q);
+        }
         {   // D_q = sum_j u_{q,j} s_j from the block-start lanes
             const int dq = lane >> LOG_RATE, dj = 1 + (lane & (RATE - 1));
             const fr_t sj = shfl_fr(s, dj);
@@ -100,17 +117,13 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const fr_t* spq = sp + q * w;
-            fr_t cst = fr_zero<PF>();
-            if (lane >= 1 && lane < T) cst = ldg(spq + T - 1 + lane);                 // w_{q,lane}
-            else if (acc_lane) { const int qq = lane - 32; if (qq == q) cst = ldg(spq); else if (qq > q) cst = ldg(P.gamma + b * 6 + qq * (qq - 1) / 2 + q); }
-            const fr_t x = fr_add<PF>(s0v, ldg(P.rc_partial + 4 * b + q));
-            const fr_t m1 = fr_mul<PF>(sq_lane ? x : cst, x);                         // slot 1
-            const fr_t x2 = shfl_fr(m1, 48);
+            const fr_t x = fr_add<PF>(s0v, rcq[q]);
+            const fr_t m1 = fr_mul<PF>(sq_lane ? x : cst[q], x);                      // slot 1
+            const fr_t x2 = bcast_fr(m1, 48);
             const fr_t x4 = fr_mul<PF>(x2, x2);                                       // slot 2
             const fr_t m3 = fr_mul<PF>(m1, x4);                                       // slot 3 (zero where cst is zero)
             s = fr_add<PF>(s, m3);
-            s0v = shfl_fr(s, 32 + q);
+            s0v = bcast_fr(s, 32 + q);
         }
     }
     if (lane == 0) s = s0v;
