@@ -17,7 +17,8 @@
 #include "fr.hpp"
 #include "dev_common.hpp"
 #include "poseidon_params.hpp"
-#include "poseidon_dev.hpp"   // TrJob
+#include "poseidon_dev.hpp"   // TrJob, c29
+#include "fr29.hpp"
 
 #if defined(__HIPCC__)
 namespace stark {
@@ -39,6 +40,58 @@ __device__ __forceinline__ fr_t bcast_fr(const fr_t& x, int src) {
     fr_t r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_readlane((int)x.v[i], src);
+    return r;
+}
+// ---- nine-limb (radix 2^29) values on the dependent chain -------------------------------------------------------
+// On a lone wave a radix-2^32 Montgomery product in a dependent chain takes 544 ns, the radix-2^29 product on nine-limb
+// values 402 ns and the square 348 ns (tools/chain_bench.hip): no carry instructions, and values stay "lazy" (any value
+// below 2^261 with limbs below 2^29 is a valid operand; a product of operands below 2^5 r comes out below ~9 r).
+__device__ __forceinline__ fr29_t shfl29(const fr29_t& x, int src) {
+    fr29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__shfl((int)x.l[i], src, 64);
+    return r;
+}
+__device__ __forceinline__ fr29_t shfl_xor29(const fr29_t& x, int m) {
+    fr29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__shfl_xor((int)x.l[i], m, 64);
+    return r;
+}
+__device__ __forceinline__ fr29_t bcast29(const fr29_t& x, int src) {
+    fr29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)x.l[i], src);
+        asm volatile("" : "+v"(r.l[i]));       // keep the copy in a VGPR: otherwise the compiler computes the next product on the (slower) scalar unit
+    }
+    return r;
+}
+__device__ __forceinline__ void carry29(fr29_t& a) {                  // limbs back below 2^29 (signed: limbs may be negative, the value is not)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a.l[i + 1] += (uint32_t)((int32_t)a.l[i] >> 29); a.l[i] &= FR_M29; }
+}
+__device__ __forceinline__ fr29_t add29(const fr29_t& a, const fr29_t& b) {     // limb-wise, no carry pass: at most 3 of these in a row
+    fr29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// value below 2^261 -> below 2r + epsilon, still >= 0: subtract k * r with k = floor(value / 2^254) - 1  (r = 2^254 + t, t < 2^126).
+// 64-bit signed limbs during the pass: k * r_i reaches 2^36.
+template <class F> __device__ __forceinline__ void lazy_reduce29(fr29_t& a) {
+    const uint32_t q = a.l[8] >> 22; const int64_t k = q ? (int64_t)q - 1 : 0;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int64_t d = (int64_t)a.l[i] - k * (int64_t)fr_p29<F>(i) + carry;
+        if (i < 8) { a.l[i] = (uint32_t)d & FR_M29; carry = d >> 29; } else a.l[8] = (uint32_t)d;
+    }
+}
+template <class F> __device__ __forceinline__ fr29_t ld29(const uint32_t* p) {   // nine limbs of a table entry; p == nullptr: zero
+    fr29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p ? p[i] : 0u;
     return r;
 }
 struct CoopLds { uint4* mds; uint4* mpre; uint4* x; };   // [T*T][2], [T*T][2], [T][2]
@@ -90,49 +143,77 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     //                 forms a_q*x (q' = q) or gamma_{q',q}*x (q' > q);  slot 2: x^4 on every lane;  slot 3: (slot 1) * x^4,
     //                 i.e. w x^5 / a x^5 / gamma x^5 without ever forming x^5 itself; one lane-wise add brings the lanes
     //                 s_j and the accumulators up to date, and accumulator lane 32+q now holds the next s0.
+    // The chain runs on nine-limb values (see above): the multiplier tables are the radix-2^29 ones of the throughput
+    // kernels (R' = 2^261 domain; a, w, gamma carry the 2^20 that x^2, x^4 and the last product lose: 2^5 each, compounded).
     constexpr int RATE = T - 1, LOG_RATE = RATE == 16 ? 4 : 3;
     static_assert(RATE == 16 || RATE == 8, "cooperative form: t = 17 or t = 9");
-    fr_t s0v = bcast_fr(s, 0);                                                        // s0, replicated on every lane
+    fr29_t sl = fr29_unpack(s);                                                       // this lane's element; lanes 32..35: accumulators
+    fr29_t s0l = bcast29(sl, 0);                                                      // s0, replicated on every lane
     const bool acc_lane = lane >= 32 && lane < 36, sq_lane = lane == 48;
     for (int b = 0; b < P.rp / 4; ++b) {
-        const fr_t* sp = P.sparse + (size_t)(4 * b) * w;
+        const size_t r0 = (size_t)(4 * b) * w;
         // this lane's multiplier for each of the four rounds, fetched up front (off the dependent chain)
-        fr_t cst[4], rcq[4];
+        fr29_t cst[4], rcq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const fr_t* spq = sp + q * w;
-            cst[q] = fr_zero<PF>();
-            if (lane >= 1 && lane < T) cst[q] = ldg(spq + T - 1 + lane);              // w_{q,lane}
-            else if (acc_lane) { const int qq = lane - 32; if (qq == q) cst[q] = ldg(spq); else if (qq > q) cst[q] = ldg(P.gamma + b * 6 + qq * (qq - 1) / 2 + q); }
-            rcq[q] = ldg(P.rc_partial + 4 * b + q);
+            const uint32_t* p = nullptr;
+            if (lane >= 1 && lane < T) p = c29(P.sparse29, r0 + q * w + T - 1 + lane);                       // w_{q,lane} * 2^20
+            else if (acc_lane) { const int qq = lane - 32; if (qq == q) p = c29(P.sparse29, r0 + q * w); else if (qq > q) p = c29(P.gamma29, b * 6 + qq * (qq - 1) / 2 + q); }
+            cst[q] = ld29<PF>(p);
+            rcq[q] = fr29_unpack(ldg(P.rc_partial + 4 * b + q));
         }
         {   // D_q = sum_j u_{q,j} s_j from the block-start lanes
             const int dq = lane >> LOG_RATE, dj = 1 + (lane & (RATE - 1));
-            const fr_t sj = shfl_fr(s, dj);
-            fr_t v = dq < 4 ? fr_mul<PF>(ldg(sp + dq * w + dj), sj) : fr_zero<PF>();
+            const fr29_t sj = shfl29(sl, dj);
+            fr29_t v = fr29_mul_mont<PF>(ld29<PF>(dq < 4 ? c29(P.sparse29, r0 + dq * w + dj) : nullptr), sj);   // u_{q,j}: not scaled
+            int pending = 0;
 #pragma unroll
-            for (int d = RATE / 2; d >= 1; d >>= 1) v = fr_add<PF>(v, shfl_xor_fr(v, d));
-            const fr_t dv = shfl_fr(v, (lane - 32) << LOG_RATE);                      // lanes 32..35 fetch D_0..D_3 (other lanes: unused)
-            if (acc_lane) s = dv;
-        }
+            for (int d = RATE / 2; d >= 1; d >>= 1) { v = add29(v, shfl_xor29(v, d)); if (++pending == 2) { carry29(v); pending = 0; } }
+            if (pending) carry29(v);
+            const fr29_t dv = shfl29(v, (lane - 32) << LOG_RATE);                     // lanes 32..35 fetch D_0..D_3 (other lanes: unused)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const fr_t x = fr_add<PF>(s0v, rcq[q]);
-            const fr_t m1 = fr_mul<PF>(sq_lane ? x : cst[q], x);                      // slot 1
-            const fr_t x2 = bcast_fr(m1, 48);
-            const fr_t x4 = fr_mul<PF>(x2, x2);                                       // slot 2
-            const fr_t m3 = fr_mul<PF>(m1, x4);                                       // slot 3 (zero where cst is zero)
-            s = fr_add<PF>(s, m3);
-            s0v = bcast_fr(s, 32 + q);
+            for (int i = 0; i < 9; ++i) sl.l[i] = acc_lane ? dv.l[i] : sl.l[i];
         }
+#define STARK_COOP_ROUND(q)                                                                       \
+        {                                                                                         \
+            fr29_t x = add29(s0l, rcq[q]); carry29(x);                                            \
+            fr29_t a1;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 9; ++i) a1.l[i] = sq_lane ? x.l[i] : cst[q].l[i]; \
+            const fr29_t m1 = fr29_mul_mont<PF>(a1, x);                        /* slot 1 */         \
+            const fr29_t x2 = bcast29(m1, 48);                                                    \
+            const fr29_t x4 = fr29_sqr_mont<PF>(x2);                           /* slot 2 */         \
+            const fr29_t m3 = fr29_mul_mont<PF>(m1, x4);                       /* slot 3 (zero where cst is zero) */ \
+            sl = add29(sl, m3); carry29(sl);                                                      \
+            s0l = bcast29(sl, 32 + q);                                                            \
+        }
+        STARK_COOP_ROUND(0) STARK_COOP_ROUND(1) STARK_COOP_ROUND(2) STARK_COOP_ROUND(3)
+#undef STARK_COOP_ROUND
+        lazy_reduce29<PF>(sl);                                                        // the lanes gained ~4r in this block
     }
-    if (lane == 0) s = s0v;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sl.l[i] = lane == 0 ? s0l.l[i] : sl.l[i];
+    lazy_reduce29<PF>(sl);
+    {   // below 2r + epsilon: pack, then two conditional subtractions (the second one fires with probability ~2^-125)
+        uint32_t tt[9];
+#pragma unroll
+        for (int wd = 0; wd < 8; ++wd) {
+            const int lo = 32 * wd, i = lo / 29, sh = lo - 29 * i;
+            uint32_t v = sl.l[i] >> sh;
+            if (i + 1 < 9) v |= sl.l[i + 1] << (29 - sh);
+            if (29 - sh + 29 < 32 && i + 2 < 9) v |= sl.l[i + 2] << (58 - sh);
+            tt[wd] = v;
+        }
+        tt[8] = 0;
+        fr_cond_sub<PF>(tt, 0u); fr_cond_sub<PF>(tt, 0u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.v[i] = tt[i];
+    }
     for (int r = half; r < P.rf; ++r) full_round(r, L.mds);
     return s;
 }
 
 // tr_hash_fields_tagged over the stream prefix || fields_i || suffix, one 64-lane block per hash i.
-__global__ void __launch_bounds__(64) k_tr_hash_coop(PoseidonDev P, TrJob J, const fr_t* __restrict__ fields, fr_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_coop(PoseidonDev P, TrJob J, const fr_t* __restrict__ fields, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
     CoopLds L = coop_setup<17>(lds, P);
     const int lane = threadIdx.x; const size_t i = blockIdx.x;
@@ -152,7 +233,7 @@ __global__ void __launch_bounds__(64) k_tr_hash_coop(PoseidonDev P, TrJob J, con
 
 // Up to 4 independent long sponges in ONE launch (one block each): the four column chains of build_f0.
 struct TrMultiJob { const fr_t* prefix[4]; int np[4]; const fr_t* suffix[4]; int ns[4]; const fr_t* fields[4]; size_t k[4]; fr_t cap; };
-__global__ void __launch_bounds__(64) k_tr_hash_coop_multi(PoseidonDev P, TrMultiJob J, fr_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_coop_multi(PoseidonDev P, TrMultiJob J, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
     CoopLds L = coop_setup<17>(lds, P);
     const int lane = threadIdx.x, b = blockIdx.x;
@@ -170,7 +251,7 @@ __global__ void __launch_bounds__(64) k_tr_hash_coop_multi(PoseidonDev P, TrMult
 
 // One Merkle node per wave (small levels: latency matters, not throughput).  Same job as k_hash_ds.
 template <int T>
-__global__ void __launch_bounds__(64) k_hash_ds_coop(PoseidonDev P, DsJob J, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_hash_ds_coop(PoseidonDev P, DsJob J, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
     CoopLds L = coop_setup<T>(lds, P);
     const int lane = threadIdx.x, rate = T - 1; const size_t k = blockIdx.x;
