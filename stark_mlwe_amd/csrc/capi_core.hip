@@ -286,7 +286,7 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, stark_params_t* p, int mode, siz
     DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
     J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
     if (!J.n_out) return STARK_OK;
-    if (use_pair(p->dev.t) && J.n_out <= 2048) {
+    if (use_pair(p->dev.t) && J.n_out <= 8192) {
         // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
         if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), ctx->stream, p->dev, J, in0, in1, out);
         else hipLaunchKernelGGL(k_hash_ds_coop<9>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(9), ctx->stream, p->dev, J, in0, in1, out);
