@@ -65,8 +65,12 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from stark_mlwe_amd.api import Context, _ptr, PALLAS_FR
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = Context(local_rank, C.c_void_p(stream))
+    # ONE real stream for torch and the library: the default stream's handle is 0, which the C-ABI reads as "make your own"
+    # (a non-blocking stream that is not ordered against torch's work), so a dedicated stream is made current for torch
+    # and handed to the context.
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    ctx = Context(local_rank, C.c_void_p(tstream.cuda_stream))
     lib = ctx.lib
 
     log_n = args.log_trace

@@ -190,6 +190,7 @@ class Context:
         if rc != 0:
             raise StarkError(rc, "stark_ctx_create failed: no usable HIP device (the product path has no CPU fallback)")
         self.h = h
+        self.stream_handle = (stream.value if isinstance(stream, C.c_void_p) else stream) or 0    # 0: the library made its own stream
         self._tparams = None
         self._mparams = {}
 

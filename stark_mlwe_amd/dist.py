@@ -22,6 +22,7 @@ Distributions (n = R * C elements, W ranks, R = 2^log_rows <= 1024 rows, C = n /
 A consumer that needs natural block order applies one more all-to-all (`DistNtt.to_natural_blocks`).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -74,20 +75,35 @@ class HipProvider:
     def __init__(self, ctx, field=0, device="cuda"):
         self.ctx, self.lib, self.field, self.device = ctx, ctx.lib, field, device
 
+    # Stream discipline.  The orchestration mixes torch device ops (slices, zeros, index gathers, staging copies, RCCL) with
+    # library kernels.  If the context was created ON torch's current stream (a real, non-default stream: bench.py does
+    # this), one stream orders everything.  Otherwise the library runs on its own non-blocking stream, which does not
+    # even synchronise with the default stream, so every library call is bracketed by explicit synchronisation.
+    def _shared(self):
+        return self.ctx.stream_handle != 0 and self.ctx.stream_handle == torch.cuda.current_stream(self.device).cuda_stream
+
+    def _run(self, fn, *args):
+        shared = self._shared()
+        if not shared:
+            torch.cuda.current_stream(self.device).synchronize()       # torch-side producers of the arguments are done
+        self.ctx._chk(fn(*args))
+        if not shared:
+            self.ctx.sync()                                            # results are visible to torch-side consumers
+
     @staticmethod
     def _p(t):
         return C.c_void_p(t.data_ptr())
 
     def ntt_columns(self, slab, log_rows, ncols, col0, log_n, inverse):
-        self.ctx._chk(self.lib.stark_ntt_columns_dev(self.ctx.h, self.field, self._p(slab), log_rows, ncols, col0, log_n, int(inverse)))
+        self._run(self.lib.stark_ntt_columns_dev, self.ctx.h, self.field, self._p(slab), log_rows, ncols, col0, log_n, int(inverse))
 
     def ntt_rows(self, slab, nrows, log_cols, inverse, scale4=None):
         from .api import _ptr
-        self.ctx._chk(self.lib.stark_ntt_rows_dev(self.ctx.h, self.field, self._p(slab), nrows, log_cols, int(inverse), _ptr(scale4)))
+        self._run(self.lib.stark_ntt_rows_dev, self.ctx.h, self.field, self._p(slab), nrows, log_cols, int(inverse), _ptr(scale4))
 
     def merkle_build(self, params, arity, tree_label, leaves, n, first_pos, level0, stop_at_len):
         h = C.c_void_p()
-        self.ctx._chk(self.lib.stark_merkle_build_dev(self.ctx.h, params.h, arity, tree_label, self._p(leaves), n, 0, None, first_pos, level0, stop_at_len, C.byref(h)))
+        self._run(self.lib.stark_merkle_build_dev, self.ctx.h, params.h, arity, tree_label, self._p(leaves), n, 0, None, first_pos, level0, stop_at_len, C.byref(h))
         return h
 
     def merkle_last_level(self, h):
@@ -95,7 +111,7 @@ class HipProvider:
         nl = self.lib.stark_merkle_num_levels(h)
         k = self.lib.stark_merkle_level_len(h, nl - 1)
         tmp = torch.empty((k, 4), dtype=torch.int64)
-        self.ctx._chk(self.lib.stark_merkle_level(h, nl - 1, C.c_void_p(tmp.data_ptr())))   # a few digests: host hop is fine
+        self._run(self.lib.stark_merkle_level, h, nl - 1, C.c_void_p(tmp.data_ptr()))   # a few digests: host hop is fine
         return tmp.to(self.device), nl
 
     def merkle_free(self, h):
@@ -120,17 +136,17 @@ class HipProvider:
     def fold(self, f, z, m):
         n = f.shape[0]
         out = self.new(n // m)
-        self.ctx._chk(self.lib.stark_fri_fold_dev(self.ctx.h, self._p(f), n, _npp(z), m, self._p(out)))
+        self._run(self.lib.stark_fri_fold_dev, self.ctx.h, self._p(f), n, _npp(z), m, self._p(out))
         return out
 
     def leaf_pair_hash(self, f, f_next, m):
         out = self.new(f.shape[0])
-        self.ctx._chk(self.lib.stark_leaf_pair_hash_dev(self.ctx.h, self.ctx.transcript_params().h, self._p(f), None if f_next is None else self._p(f_next), f.shape[0], m, self._p(out)))
+        self._run(self.lib.stark_leaf_pair_hash_dev, self.ctx.h, self.ctx.transcript_params().h, self._p(f), None if f_next is None else self._p(f_next), f.shape[0], m, self._p(out))
         return out
 
     def merkle_build_pairs(self, params, arity, tree_label, f, cp, n):
         h = C.c_void_p()
-        self.ctx._chk(self.lib.stark_merkle_build_dev(self.ctx.h, params.h, arity, tree_label, self._p(f), n, 1, self._p(cp), 0, 0, 0, C.byref(h)))
+        self._run(self.lib.stark_merkle_build_dev, self.ctx.h, params.h, arity, tree_label, self._p(f), n, 1, self._p(cp), 0, 0, 0, C.byref(h))
         return h
 
     def merkle_num_levels(self, h):
@@ -144,13 +160,13 @@ class HipProvider:
         import numpy as np
         ix = np.ascontiguousarray(idx, dtype=np.uint64)
         out = np.zeros((len(ix), 4), np.uint64)
-        self.ctx._chk(self.lib.stark_merkle_gather(h, lvl, ix.ctypes.data_as(C.c_void_p), len(ix), out.ctypes.data_as(C.c_void_p)))
+        self._run(self.lib.stark_merkle_gather, h, lvl, ix.ctypes.data_as(C.c_void_p), len(ix), out.ctypes.data_as(C.c_void_p))
         return out
 
     def column_digest(self, tag: bytes, col):
         """tr_hash_fields_tagged(tag, column) — the serial sponge of build_f0 (fri.rs:551-554); numpy (4,)."""
         out = self.new(1)
-        self.ctx._chk(self.lib.stark_tr_hash_fields_tagged_dev(self.ctx.h, None, tag, self._p(col), col.shape[0], 1, self._p(out)))
+        self._run(self.lib.stark_tr_hash_fields_tagged_dev, self.ctx.h, None, tag, self._p(col), col.shape[0], 1, self._p(out))
         self.ctx.sync()
         return out.cpu().numpy().view("uint64")[0]
 
@@ -159,7 +175,7 @@ class HipProvider:
 
     def ali_merge_shard(self, a, s, e, t, z, j0, n_global):
         f0 = self.new(a.shape[0])
-        self.ctx._chk(self.lib.stark_ali_merge_shard_dev(self.ctx.h, self._p(a), self._p(s), self._p(e), self._p(t), None, None, None, _npp(z), a.shape[0], j0, n_global, self._p(f0), None))
+        self._run(self.lib.stark_ali_merge_shard_dev, self.ctx.h, self._p(a), self._p(s), self._p(e), self._p(t), None, None, None, _npp(z), a.shape[0], j0, n_global, self._p(f0), None)
         return f0
 
     def query_plan(self, roots, n0, schedule, r):
@@ -404,6 +420,12 @@ class DistProver:
                 rt, _ = p.merkle_last_level(lay.tree)
                 roots.append(rt[0].cpu().numpy().view(np.uint64))
         self.roots = np.stack(roots)
+        if os.environ.get("STARK_DIST_CHECK"):        # diagnostic: every rank must hold the same roots
+            mine = torch.from_numpy(self.roots.view(np.int64).copy())
+            allr = all_gather_rows(mine.view(1, -1)).view(W, -1)
+            if not bool((allr == allr[0]).all()):
+                bad = [l for l in range(L + 1) if not bool((allr.view(W, L + 1, 4)[:, l] == allr.view(W, L + 1, 4)[0, l]).all())]
+                raise RuntimeError(f"rank {rank}: roots differ between ranks at layers {bad} (sharded flags {[bool(x.sharded) for x in self.layers]})")
         return self.roots
 
     # -- fri_prove_queries + encoding (fri.rs:355-466, 613-640) -------------------------------------------

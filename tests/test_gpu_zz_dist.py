@@ -91,7 +91,14 @@ def _prove_worker(rank, world, port, log_n0, schedule, r, q):
         from stark_mlwe_amd import dist as sd
         from stark_mlwe_amd.api import Context, DeepFriParams
         torch.cuda.set_device(0)
-        ctx = Context(0); o = oracle_lib.Oracle(); prov = sd.HipProvider(ctx)
+        if log_n0 >= 16:      # one stream for torch and the library (what bench.py does) ...
+            import ctypes as C
+            ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+            ctx = Context(0, C.c_void_p(ts.cuda_stream))
+        else:                 # ... or the library on its own stream: the provider then brackets every call with explicit syncs
+            ctx = Context(0)
+        o = oracle_lib.Oracle(); prov = sd.HipProvider(ctx)
+        assert prov._shared() == (log_n0 >= 16)
         n0 = 1 << log_n0; nl = n0 // world
         cols = [o.synth_column(0x5EED0000 + log_n0, c, 0, n0) for c in range(4)]
         mine = [torch.from_numpy(c[rank * nl:(rank + 1) * nl].view(np.int64).copy()).cuda() for c in cols]
