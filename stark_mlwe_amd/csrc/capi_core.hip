@@ -29,6 +29,11 @@ int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out) {
     *out = ctx->scratch; return STARK_OK;
 }
 
+int32_t ctx_side_stream(stark_ctx* ctx, hipStream_t* out) {
+    if (!ctx->side_stream) { STARK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)); STARK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); }
+    *out = ctx->side_stream; return STARK_OK;
+}
+
 static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     if (host::rp_for_width(P->ref.t) < 0) return ctx->fail(STARK_ERR_UNSUPPORTED, "Poseidon width must be one of 9,17,33,65,129");
     P->kc = host::make_kernel_consts(P->ref);
@@ -197,6 +202,8 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (ctx->leaf_init) (void)hipFree(ctx->leaf_init);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0); if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx; return STARK_OK;

@@ -82,36 +82,48 @@ static int32_t fri_build_impl(stark_ctx* ctx, const fr_t* f0_dev, size_t n0, con
         S->f.push_back(nx); S->n.push_back(nn);
         int32_t rc = fold_dev(ctx, S->f[l], S->n[l], z, schedule[l], nx); if (rc) return bail(rc);
     }
-    // commitments of all L+1 layers (independent jobs)
-    for (size_t l = 0; l <= L; ++l) {
+    // Commitments of all L+1 layers (independent jobs).  Layer 0 is ~94 % of the hashing and fills the GPU; the later layers
+    // are small and mostly LATENCY-bound (tree tops: one dependent permutation per level), so they are enqueued first on a
+    // side stream and run underneath layer 0 instead of after it.  Temporaries stay alive until both streams have drained
+    // (a hipFree in between would synchronise the device and serialise the two again).
+    hipStream_t main_stream = ctx->stream, side = nullptr;
+    { int32_t rc = ctx_side_stream(ctx, &side); if (rc) return bail(rc); }
+    if (hipEventRecord(ctx->ev_fork, main_stream) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_fork, 0) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "fork"));
+    std::vector<DevBuf> keep(2 * (L + 1) + 1);
+    size_t nkeep = 0;
+    S->trees.assign(L + 1, nullptr); S->hashed.assign(L + 1, 0); S->arity.assign(L + 1, 0);
+    auto commit_layer = [&](size_t l) -> int32_t {
         size_t n = S->n[l], m_l = l < L ? schedule[l] : 1, arity = pick_arity_for_layer(n, m_l); bool hashed = hashed_arity(arity);
-        stark_params* mp = nullptr; { int32_t rc = ctx_merkle_params(ctx, host::width_for_arity(arity), &mp); if (rc) return bail(rc); }    // MerkleChannelCfg::new(arity), fri.rs:277
-        stark_tree* T = nullptr; int32_t rc;
+        stark_params* mp = nullptr; STARK_TRY(ctx_merkle_params(ctx, host::width_for_arity(arity), &mp));    // MerkleChannelCfg::new(arity), fri.rs:277
+        stark_tree* T = nullptr;
         if (hashed) {
-            DevBuf h; if (h.alloc(n * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "leaf digests"));
-            rc = stark_leaf_pair_hash_dev(ctx, tp, (const uint64_t*)S->f[l], l < L ? (const uint64_t*)S->f[l + 1] : nullptr, n, m_l, (uint64_t*)h.p);     // fri.rs:283 (s = f_{l+1}[i/m] view)
-            if (rc) return bail(rc);
-            rc = stark_merkle_build_dev(ctx, mp, arity, (uint64_t)l, (const uint64_t*)h.p, n, 0, nullptr, 0, 0, 0, &T);
-            if (rc) return bail(rc);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { stark_merkle_free(T); return bail(ctx->fail(STARK_ERR_HIP, "sync")); }
+            DevBuf& h = keep[nkeep++]; if (h.alloc(n * sizeof(fr_t)) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "leaf digests");
+            STARK_TRY(stark_leaf_pair_hash_dev(ctx, tp, (const uint64_t*)S->f[l], l < L ? (const uint64_t*)S->f[l + 1] : nullptr, n, m_l, (uint64_t*)h.p));     // fri.rs:283 (s = f_{l+1}[i/m] view)
+            STARK_TRY(stark_merkle_build_dev(ctx, mp, arity, (uint64_t)l, (const uint64_t*)h.p, n, 0, nullptr, 0, 0, 0, &T));
         } else {
             // commit_pairs(f_l, s_l) (fri.rs:289): s_l is the m-fold replication of f_{l+1}, or zeros on the last layer (fri.rs:266)
-            DevBuf s; if (s.alloc(n * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "s layer"));
+            DevBuf& sl = keep[nkeep++]; if (sl.alloc(n * sizeof(fr_t)) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "s layer");
             if (l < L) {
                 std::vector<uint64_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i / m_l;
-                DevBuf di; if (di.alloc(n * 8) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "s idx"));
-                if (hipMemcpyAsync(di.p, idx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "copy idx"));
-                hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t*)S->f[l + 1], (const uint64_t*)di.p, (uint64_t)n, s.fr());
-                if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "gather s"));
-            } else if (hipMemsetAsync(s.p, 0, n * sizeof(fr_t), ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "memset"));
-            rc = stark_merkle_build_dev(ctx, mp, arity, (uint64_t)l, (const uint64_t*)S->f[l], n, 1, (const uint64_t*)s.p, 0, 0, 0, &T);
-            if (rc) return bail(rc);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { stark_merkle_free(T); return bail(ctx->fail(STARK_ERR_HIP, "sync")); }
+                DevBuf& di = keep[nkeep++]; if (di.alloc(n * 8) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "s idx");
+                if (hipMemcpyAsync(di.p, idx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return ctx->fail(STARK_ERR_HIP, "copy idx");
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) return ctx->fail(STARK_ERR_HIP, "idx upload");     // idx is a host temporary
+                hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t*)S->f[l + 1], (const uint64_t*)di.p, (uint64_t)n, sl.fr());
+            } else if (hipMemsetAsync(sl.p, 0, n * sizeof(fr_t), ctx->stream) != hipSuccess) return ctx->fail(STARK_ERR_HIP, "memset");
+            STARK_TRY(stark_merkle_build_dev(ctx, mp, arity, (uint64_t)l, (const uint64_t*)S->f[l], n, 1, (const uint64_t*)sl.p, 0, 0, 0, &T));
         }
-        S->trees.push_back(T); S->hashed.push_back(hashed ? 1 : 0); S->arity.push_back(arity);
-        fr_t root; rc = stark_merkle_root(T, (uint64_t*)&root); if (rc) return bail(rc);
-        S->roots.push_back(root);
-    }
+        S->trees[l] = T; S->hashed[l] = hashed ? 1 : 0; S->arity[l] = arity;
+        return STARK_OK;
+    };
+    int32_t crc = STARK_OK;
+    ctx->stream = side;
+    for (size_t l = L; l >= 1 && crc == STARK_OK; --l) crc = commit_layer(l);
+    ctx->stream = main_stream;
+    if (crc == STARK_OK) crc = commit_layer(0);
+    const bool drained = hipStreamSynchronize(side) == hipSuccess && hipStreamSynchronize(main_stream) == hipSuccess;
+    if (crc != STARK_OK) return bail(crc);
+    if (!drained) return bail(ctx->fail(STARK_ERR_HIP, "sync"));
+    for (size_t l = 0; l <= L; ++l) { fr_t root; int32_t rc = stark_merkle_root(S->trees[l], (uint64_t*)&root); if (rc) return bail(rc); S->roots.push_back(root); }
     *out = S; return STARK_OK;
 }
 

@@ -30,8 +30,10 @@ struct stark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side_stream = nullptr;               // lazily created: small independent jobs that run underneath a big one (fri_build)
     std::string err;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;         // stark_timer_start / stop
+    hipEvent_t ev_fork = nullptr;                    // orders the side stream after the main one
     // lazily created constants
     stark_params* tparams = nullptr;                 // transcript params (t=17, "POSEIDON-T17-X5-TRANSCRIPT")
     std::map<int, stark_params*> merkle_params;      // poseidon_params_for_width(t)
@@ -85,6 +87,7 @@ int32_t merkle_open_host(stark_tree* t, const std::vector<size_t>& indices, Merk
 int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out);
 int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out);
 int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out);
+int32_t ctx_side_stream(stark_ctx* ctx, hipStream_t* out);
 void ntt_plans_free(stark_ctx* ctx);
 int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev);
 int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev);
