@@ -19,7 +19,11 @@ struct NttPlan {
     fr_t* scale = nullptr;                            // n^-1 (inverse plans)
     // coset cache (one coset value at a time)
     bool have_coset = false; fr_t coset; DevTable coset_tab;
+    // direct tables (log_n <= 24): inter-pass twiddles of the strided passes, coset pre-scale
+    fr_t* tw_direct[2] = {nullptr, nullptr}; fr_t* coset_direct = nullptr;
     ~NttPlan() {
+        for (auto p : tw_direct) if (p) (void)hipFree(p);
+        if (coset_direct) (void)hipFree(coset_direct);
         for (auto p : stage_tw) if (p) (void)hipFree(p);
         if (root.lo) (void)hipFree(root.lo); if (root.hi) (void)hipFree(root.hi); if (scale) (void)hipFree(scale);
         if (coset_tab.lo) (void)hipFree(coset_tab.lo); if (coset_tab.hi) (void)hipFree(coset_tab.hi);
@@ -29,6 +33,9 @@ struct NttPlan {
 }  // namespace stark
 
 static const size_t kMaxLds = 160 * 1024;
+// direct (one-product) twiddle / coset tables for transforms up to 2^STARK_NTT_DIRECT points (default 24; 0 disables): they cost
+// n*32 B of HBM per strided pass and plan, which the VALU-bound transform does not notice, and save a product per element and pass
+static inline int ntt_direct_max() { static const int v = [] { const char* e = getenv("STARK_NTT_DIRECT"); return e ? atoi(e) : 24; }(); return v; }
 
 template <class F>
 static int32_t fill_table(stark_ctx* ctx, const fr_t& g, const fr_t& c0, int lo_bits, int hi_bits, DevTable& T) {
@@ -57,6 +64,14 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
         int lb = p->log_b[i]; fr_t wb = fr_root_of_unity<F>((unsigned)lb); if (inverse) wb = fr_inv<F>(wb);
         DevTable T; int32_t rc = fill_table<F>(ctx, wb, fr_one<F>(), lb > 0 ? lb - 1 : 0, 0, T); if (rc) return bail(rc);
         p->stage_tw[i] = T.lo; (void)hipFree(T.hi);
+    }
+    if (ntt_direct_max() >= log_n) {       // direct twiddle tables: 2^log_m entries per strided pass
+        int rem = log_n;
+        for (int i = 0; i + 1 < p->P; ++i) {
+            if (hipMalloc((void**)&p->tw_direct[i], ((size_t)1 << rem) * sizeof(fr_t)) != hipSuccess) { p->tw_direct[i] = nullptr; (void)hipGetLastError(); break; }   // no memory: keep the two-level lookup
+            hipLaunchKernelGGL(k_fill_tw_direct<F>, dim3((unsigned)((((uint64_t)1 << rem) + 255) / 256)), dim3(256), 0, ctx->stream, p->root.view(), log_n, rem, p->log_b[i], p->tw_direct[i]);
+            rem -= p->log_b[i];
+        }
     }
     if (inverse) {
         fr_t ninv = fr_inv<F>(fr_from_u64<F>(1ull << log_n));
@@ -115,9 +130,14 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
             if (!inverse) STARK_TRY(fill_table<F>(ctx, *coset, fr_one<F>(), lo_bits, hi_bits, p->coset_tab));                       // g^j
             else STARK_TRY(fill_table<F>(ctx, fr_inv<F>(*coset), fr_inv<F>(fr_from_u64<F>(1ull << log_n)), lo_bits, hi_bits, p->coset_tab));   // n^-1 g^-k
             p->coset = *coset; p->have_coset = true;
+            if (p->coset_direct) { (void)hipFree(p->coset_direct); p->coset_direct = nullptr; }
+            if (!inverse && ntt_direct_max() >= log_n && hipMalloc((void**)&p->coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess)
+                hipLaunchKernelGGL(k_fill_pow_direct<F>, dim3((unsigned)((((uint64_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, p->coset_tab.view(), 1ull << log_n, p->coset_direct);
+            else (void)hipGetLastError();
         }
         if (!inverse) pre = p->coset_tab.view(); else post = p->coset_tab.view();
     }
+    const fr_t* pre_direct = (coset && !inverse) ? p->coset_direct : nullptr;
     const uint64_t total = batch << log_n;
     fr_t* scratch = nullptr;
     if (p->P > 1) { void* s = nullptr; STARK_TRY(ctx_scratch(ctx, total * sizeof(fr_t), &s)); scratch = (fr_t*)s; }
@@ -128,11 +148,11 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     for (int i = 0; i + 1 < p->P; ++i) {   // strided passes
         A.log_b = p->log_b[i]; A.log_m = rem; A.stride = 1ull << (rem - A.log_b);
         A.log_c = pick_log_c(A.log_b, rem - A.log_b, log_n);
-        A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none;
+        A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none; A.pre_direct = (i == 0) ? pre_direct : nullptr; A.tw_direct = p->tw_direct[i];
         STARK_TRY(launch_strided<F>(ctx, A, total, src, scratch));
         src = scratch; rem -= A.log_b;
     }
-    A.pre = (p->P == 1) ? pre : none;
+    A.pre = (p->P == 1) ? pre : none; A.pre_direct = nullptr; A.tw_direct = nullptr;
     A.log_b = p->log_b[p->P - 1]; A.stage_tw = p->stage_tw[p->P - 1];
     A.log_b1 = p->P >= 2 ? p->log_b[0] : 0; A.log_b2 = p->P == 3 ? p->log_b[1] : 0;
     A.log_c = p->P == 1 ? 0 : pick_log_c(A.log_b, A.log_b1, log_n);

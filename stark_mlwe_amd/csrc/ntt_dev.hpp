@@ -44,6 +44,9 @@ struct NttPassArgs {
     const fr_t* scale;    // plain inverse: n^-1 (nullptr => none)
     uint64_t rest0;       // strided pass: global index of this slab's first column (multi-GPU column blocks); 0 otherwise
     int log_vec;          // last pass: log2 of the length of one vector when several are batched (== log_b+log_b1+log_b2)
+    // Direct tables (plans up to 2^24 points): one product per element instead of the two of the two-level lookup.
+    const fr_t* tw_direct;   // strided pass: w_m^(rest*k) at index k*stride + rest (the layout of the sub-problem); nullptr => `root` lookup
+    const fr_t* pre_direct;  // first pass: g^j at index j; nullptr => `pre` lookup
 };
 
 __device__ __forceinline__ fr_t lds_ld(const uint4* lo, const uint4* hi, int slot) {
@@ -129,7 +132,7 @@ __device__ __forceinline__ void tail_store(const NttPassArgs& A, const uint4* dl
             fr_t y = x[p];
             if (STRIDED) {
                 const uint64_t e = (rest * k) << sh;
-                if (e) y = fr_mul<F>(y, pow_lookup<F>(A.root, e));
+                if (e) y = fr_mul<F>(y, A.tw_direct ? ldg(A.tw_direct + (uint64_t)k * A.stride + (rest - A.rest0)) : pow_lookup<F>(A.root, e));
                 stg(dst + (uint64_t)k * A.stride + c, y);
             } else {
                 const uint64_t out = ((uint64_t)k << (A.log_b1 + A.log_b2)) + (k2 << A.log_b1) + k1_0 + c;
@@ -155,7 +158,8 @@ __global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttP
         const int c = idx & (C - 1), p = idx >> A.log_c;
         const uint64_t g = base + (uint64_t)p * A.stride + c;
         fr_t x = ldg(src + g);
-        if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, g));
+        if (A.pre_direct) x = fr_mul<F>(x, ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1))));
+        else if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, g));
         lds_st(dlo, dhi, idx, x);
     }
     __syncthreads();
@@ -211,6 +215,21 @@ __global__ void k_fill_pow_table(fr_t* lo, fr_t* hi, int lo_bits, int hi_bits, f
         while (e) { if (e & 1) acc = fr_mul<F>(acc, b); b = fr_sqr<F>(b); e >>= 1; }
         stg(hi + (i - nlo), acc);
     }
+}
+// Direct inter-pass twiddle table of one strided pass: out[k*S + rest] = w_m^(rest*k), S = 2^(log_m - log_b).
+template <class F>
+__global__ void k_fill_tw_direct(PowTable root, int log_n, int log_m, int log_b, fr_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_m) return;
+    const int ls = log_m - log_b;
+    const uint64_t k = i >> ls, rest = i & ((1ull << ls) - 1);
+    stg(out + i, pow_lookup<F>(root, (rest * k) << (log_n - log_m)));
+}
+// out[j] = c0 * g^j via the two-level table (coset pre-scale, direct form)
+template <class F>
+__global__ void k_fill_pow_direct(PowTable t, uint64_t n, fr_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stg(out + i, pow_lookup<F>(t, i));
 }
 template <class F>
 __global__ void k_zero_fill(fr_t* p, uint64_t n) {
