@@ -522,3 +522,26 @@ def test_full_size_proof_accepted_by_reference_verifier(gpu_ctx, oracle, log_n0)
     assert proof2 == proof and est2 == est
     bad = bytearray(proof); bad[len(bad) // 2] ^= 0x10
     assert oracle.deep_fri_verify(bytes(bad), sched, r, 0xDEEFBAAD) == 0
+
+
+def test_ntt_two_level_twiddle_path_matches_direct_tables(gpu_ctx, oracle):
+    """Transforms above 2^24 points (BASELINE's 2^26 config) take the two-level power-table lookup instead of the direct
+    twiddle / coset tables.  The same code path is forced at 2^21 in a child process (STARK_NTT_DIRECT=0, read once per
+    process) and must give the bytes of the direct-table path, for the plain and the coset transform, forward and inverse."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import oracle_lib; from stark_mlwe_amd.api import Context, PALLAS_FR\n"
+        "o = oracle_lib.Oracle(); c = Context(0); x = o.synth_column(21, 7, 0, 1 << 21); g = o.from_u64(5)\n"
+        "y = c.fft(x, field=PALLAS_FR); z = c.fft(x, field=PALLAS_FR, coset=g); w = c.ifft(z, field=PALLAS_FR, coset=g)\n"
+        "print(hashlib.sha256(y.tobytes() + z.tobytes()).hexdigest(), bool((w == x).all())); c.close()\n" % (root, root))
+    env = dict(os.environ, STARK_NTT_DIRECT="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    digest, roundtrip = out.stdout.split()[-2:]
+    x = oracle.synth_column(21, 7, 0, 1 << 21); g = oracle.from_u64(5)
+    y = gpu_ctx.fft(x, field=PALLAS_FR); z = gpu_ctx.fft(x, field=PALLAS_FR, coset=g)
+    assert roundtrip == "True"
+    assert digest == hashlib.sha256(y.tobytes() + z.tobytes()).hexdigest()
+    assert (gpu_ctx.ifft(z, field=PALLAS_FR, coset=g) == x).all()

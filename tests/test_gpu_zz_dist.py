@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _rendezvous_env(port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["STARK_DIST_CHECK"] = "1"                    # DistProver compares the roots across ranks before the query phase
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # loopback only: never resolve the box's hostname
 
 
