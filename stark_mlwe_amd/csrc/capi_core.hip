@@ -43,7 +43,7 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds), o_mpre = put(k.mds_pre), o_gam = put(k.gamma);
     // radix-2^29 multiplier tables (fr29.hpp), appended to the same device blob as raw words
     const size_t o_29 = blob.size();
-    { std::vector<uint32_t> w29; for (auto* v : {&k.lu29, &k.lu_pre29, &k.row0_29, &k.sparse29, &k.gamma29}) w29.insert(w29.end(), v->begin(), v->end());
+    { std::vector<uint32_t> w29; for (auto* v : {&k.lu29, &k.lu_pre29, &k.row0_29, &k.sparse29, &k.gamma29, &k.mds29, &k.mds_pre29}) w29.insert(w29.end(), v->begin(), v->end());
       while (w29.size() % 8) w29.push_back(0);
       blob.resize(o_29 + w29.size() / 8); memcpy((void*)(blob.data() + o_29), w29.data(), w29.size() * 4); }
     STARK_HIP(ctx, hipMalloc((void**)&P->blob, blob.size() * sizeof(fr_t)));
@@ -54,7 +54,8 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     P->dev.row0 = P->blob + o_row0; P->dev.sparse = P->blob + o_sp; P->dev.mds = P->blob + o_mds; P->dev.mds_pre = P->blob + o_mpre; P->dev.gamma = P->blob + o_gam;
     { const uint32_t* b29 = reinterpret_cast<const uint32_t*>(P->blob + o_29);
       P->dev.lu29 = b29; P->dev.lu_pre29 = b29 + k.lu29.size(); P->dev.row0_29 = P->dev.lu_pre29 + k.lu_pre29.size();
-      P->dev.sparse29 = P->dev.row0_29 + k.row0_29.size(); P->dev.gamma29 = P->dev.sparse29 + k.sparse29.size(); }
+      P->dev.sparse29 = P->dev.row0_29 + k.row0_29.size(); P->dev.gamma29 = P->dev.sparse29 + k.sparse29.size();
+      P->dev.mds29 = P->dev.gamma29 + k.gamma29.size(); P->dev.mds_pre29 = P->dev.mds29 + k.mds29.size(); }
     return STARK_OK;
 }
 static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c, stark_params** out) {

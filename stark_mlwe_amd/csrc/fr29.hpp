@@ -75,6 +75,13 @@ FR_HD void fr_wide29_mac(fr_wide29& w, const uint32_t* __restrict__ a_, const fr
         for (int j = 0; j < 9; ++j) w.c[i + j] += (uint64_t)ai * b.l[j];
     }
 }
+// the same with the constant's limbs already in registers (e.g. read from LDS)
+FR_HD void fr_wide29_mac_regs(fr_wide29& w, const uint32_t* a, const fr29_t& b) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w.c[i + j] += (uint64_t)a[i] * b.l[j];
+}
 // carry pass: columns 0..16 back below 2^29, the excess moves up (column 17 absorbs the top)
 FR_HD void fr_wide29_norm(fr_wide29& w) {
 #pragma unroll

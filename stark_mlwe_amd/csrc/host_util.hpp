@@ -201,6 +201,7 @@ struct KernelConsts {
     std::vector<fr_t> gamma;            // (rp/4)*6: blocks of 4 partial rounds, gamma[q(q-1)/2+p] = sum_j u_{q,j} w_{p,j} (p < q)
     // the multiplier tables of every dot product again, as nine 29-bit limbs of c*2^261 mod r per entry (fr29.hpp)
     std::vector<uint32_t> lu29, lu_pre29, row0_29, sparse29, gamma29;
+    std::vector<uint32_t> mds29, mds_pre29;   // dense forms for the one-wave kernel (every entry meets an S-box output: all scaled)
     bool ok = false;
 };
 // scaled(i) == true: the entry multiplies an S-box output, which fr_pow5_r29 delivers as x^5 / 2^20 (fr29.hpp)
@@ -283,6 +284,7 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     const auto a_and_w = [t](size_t i) { const int c = (int)(i % (2 * t - 1)); return c == 0 || c >= t; };
     k.lu29 = to_radix29(k.lu, upper); k.lu_pre29 = to_radix29(k.lu_pre, upper); k.row0_29 = to_radix29(k.row0, all);
     k.sparse29 = to_radix29(k.sparse, a_and_w); k.gamma29 = to_radix29(k.gamma, all);
+    k.mds29 = to_radix29(k.mds, all); k.mds_pre29 = to_radix29(k.mds_pre, all);
     k.ok = true;
     return k;
 }

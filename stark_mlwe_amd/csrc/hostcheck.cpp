@@ -22,7 +22,7 @@ static void bind(HcParams* P) {
     P->kc = host::make_kernel_consts(P->ref);
     P->dev.t = P->kc.t; P->dev.rf = P->kc.rf; P->dev.rp = P->kc.rp; P->dev.rc_full = P->kc.rc_full.data(); P->dev.rc_partial = P->kc.rc_partial.data();
     P->dev.lu = P->kc.lu.data(); P->dev.lu_pre = P->kc.lu_pre.data(); P->dev.row0 = P->kc.row0.data(); P->dev.sparse = P->kc.sparse.data(); P->dev.mds = P->kc.mds.data(); P->dev.mds_pre = P->kc.mds_pre.data(); P->dev.gamma = P->kc.gamma.data();
-    P->dev.lu29 = P->kc.lu29.data(); P->dev.lu_pre29 = P->kc.lu_pre29.data(); P->dev.row0_29 = P->kc.row0_29.data(); P->dev.sparse29 = P->kc.sparse29.data(); P->dev.gamma29 = P->kc.gamma29.data();
+    P->dev.lu29 = P->kc.lu29.data(); P->dev.lu_pre29 = P->kc.lu_pre29.data(); P->dev.row0_29 = P->kc.row0_29.data(); P->dev.sparse29 = P->kc.sparse29.data(); P->dev.gamma29 = P->kc.gamma29.data(); P->dev.mds29 = P->kc.mds29.data(); P->dev.mds_pre29 = P->kc.mds_pre29.data();
 }
 
 extern "C" {

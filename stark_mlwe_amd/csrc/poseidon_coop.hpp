@@ -94,7 +94,7 @@ template <class F> __device__ __forceinline__ fr29_t ld29(const uint32_t* p) {  
     for (int i = 0; i < 9; ++i) r.l[i] = p ? p[i] : 0u;
     return r;
 }
-struct CoopLds { uint4* mds; uint4* mpre; uint4* x; };   // [T*T][2], [T*T][2], [T][2]
+struct CoopLds { uint32_t* mds; uint4* x; };   // [T*T][9] (nine 29-bit limbs, 2^261 domain, x 2^20), [T][2] (packed elements)
 __device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
     uint4 lo = base[2 * idx], hi = base[2 * idx + 1];
     fr_t x; x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w; return x;
@@ -102,10 +102,17 @@ __device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
 __device__ __forceinline__ void lds_put(uint4* base, int idx, const fr_t& x) {
     base[2 * idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]); base[2 * idx + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
-static inline size_t coop_lds_bytes(int t) { return (size_t)(t * t * 2 * 2 + t * 2) * 16; }
+// LDS: x first (16-byte slots), then M as plain words, 36 B per entry (10.7 KiB for t = 17: LDS never limits the number of
+// one-wave workgroups per CU).  B_1*M is used by ONE of the eight full rounds and is read from global memory there.
+static inline size_t coop_lds_bytes(int t) { return (size_t)t * 2 * 16 + (size_t)t * t * 9 * 4; }
+__device__ __forceinline__ void lds_get29(const uint32_t* base, int idx, uint32_t* a) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = base[9 * idx + i];
+}
 template <int T> __device__ __forceinline__ CoopLds coop_setup(uint4* lds, const PoseidonDev& P) {
-    CoopLds L{lds, lds + T * T * 2, lds + T * T * 4};
-    for (int k = threadIdx.x; k < T * T; k += 64) { lds_put(L.mds, k, ldg(P.mds + k)); lds_put(L.mpre, k, ldg(P.mds_pre + k)); }
+    uint32_t* m = reinterpret_cast<uint32_t*>(lds + T * 2);
+    CoopLds L{m, lds};
+    for (int k = threadIdx.x; k < T * T * 9; k += 64) L.mds[k] = P.mds29[k];                                    // coalesced word copies
     __syncthreads();
     return L;
 }
@@ -119,15 +126,21 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     const int row = lane % T, q = lane / T;
     const int j0 = q * PER, j1 = (j0 + PER < T) ? j0 + PER : T;
     const bool elem = lane < T;
-    auto full_round = [&](int r, const uint4* M) {
-        if (elem) { s = fr_pow5<PF>(fr_add<PF>(s, ldg(P.rc_full + r * T + lane))); lds_put(L.x, lane, s); }
+    auto full_round = [&](int r, const uint32_t* M, const bool in_lds) {
+        if (elem) { s = fr_pow5_r29<PF>(fr_add<PF>(s, ldg(P.rc_full + r * T + lane))); lds_put(L.x, lane, s); }    // x^5 / 2^20: the matrices carry the 2^20
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         fr_t part = fr_zero<PF>();
         if (q < NS && j0 < T) {
-            fr_wide acc; fr_wide_zero(acc);
-            for (int j = j0; j < j1; ++j) fr_wide_mac_f<PF>(acc, lds_get(M, row * T + j), lds_get(L.x, j));
-            part = fr_wide_reduce<PF>(acc);
+            static_assert(PER <= fr29_max_terms<PF>(), "row segment within one carry-free run");
+            fr_wide29 acc; fr_wide29_zero(acc);
+            for (int j = j0; j < j1; ++j) {
+                uint32_t a[9];
+                if (in_lds) lds_get29(M, row * T + j, a);
+                else { _Pragma("unroll") for (int i = 0; i < 9; ++i) a[i] = P.mds_pre29[9 * (row * T + j) + i]; }
+                fr_wide29_mac_regs(acc, a, fr29_unpack(lds_get(L.x, j)));
+            }
+            part = fr_wide29_reduce<PF>(acc);
         }
         fr_t tot = part;
 #pragma unroll
@@ -135,7 +148,7 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
         if (elem) s = tot;
         __builtin_amdgcn_wave_barrier();
     };
-    for (int r = 0; r < half; ++r) full_round(r, r == half - 1 ? L.mpre : L.mds);
+    for (int r = 0; r < half; ++r) full_round(r, L.mds, r != half - 1);
     // Partial rounds in blocks of 4 (the algebra of permute_core, poseidon_dev.hpp), three product latencies per round:
     //   block start : all 4*(T-1) products u_{q,j}*s_j at once (lane (q, j)), butterfly-summed per round -> D_q, parked
     //                 in the "accumulator" lanes 32+q of the state register;
@@ -208,7 +221,7 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
 #pragma unroll
         for (int i = 0; i < 8; ++i) s.v[i] = tt[i];
     }
-    for (int r = half; r < P.rf; ++r) full_round(r, L.mds);
+    for (int r = half; r < P.rf; ++r) full_round(r, L.mds, true);
     return s;
 }
 
