@@ -502,14 +502,14 @@ def test_gpu_proof_tamper_rejected(gpu_ctx, oracle):
     assert rejected >= 5      # roots, siblings, opened values: caught; the trailing (n0, omega) words are not read by the reference's verifier
 
 
-@pytest.mark.parametrize("log_n0", [20, 23])
-def test_full_size_proof_accepted_by_reference_verifier(gpu_ctx, oracle, log_n0):
+@pytest.mark.parametrize("log_n0,r", [(20, 32), (22, 40), (23, 32)])
+def test_full_size_proof_accepted_by_reference_verifier(gpu_ctx, oracle, log_n0, r):
     """BASELINE sizes (2^20 trace; 2^23 = its blow-up-8 extension): the commit + query phases on the GPU, then
     deep_fri_verify (fri.rs:643-762, oracle restatement) on the proof bytes — every opened leaf, every Merkle
     multiproof up to the L+1 roots and the final layer must check out; the sharded code path must agree byte for byte."""
     import torch
     from stark_mlwe_amd import dist as sd
-    n0, sched, r = 1 << log_n0, [16, 16, 8], 32
+    n0, sched = 1 << log_n0, [16, 16, 8]        # (22, 40) is BASELINE configs[2]: 2^22 trace, full FRI, 40 queries
     f0 = torch.empty((n0, 4), dtype=torch.int64, device="cuda")
     gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, 0x5EED0000 + log_n0, 5, 0, n0, C.c_void_p(f0.data_ptr())))
     sch = np.ascontiguousarray(sched, dtype=np.uint64); h = C.c_void_p()
