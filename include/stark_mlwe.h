@@ -16,7 +16,15 @@
  *   - Every function returns a status: 0 = OK, negative = error class.  stark_last_error() gives text.
  *     The Rust wrappers turn non-zero into panic!, matching the reference's assert!/panic! behaviour
  *     (fri.rs:86-87, merkle/src/lib.rs:148,161).
- *   - One context may be used by one host thread at a time; distinct contexts are independent.
+ *   - One context may be used by one host thread at a time; distinct contexts are independent (every
+ *     entry point makes its context's device current, so one process may hold contexts on several GPUs).
+ *   - Stream rule: all work of a context is enqueued on ONE stream, chosen at stark_ctx_create.  A caller
+ *     that produces inputs or consumes outputs with its own kernels (torch, hipMemcpyAsync, ...) must do
+ *     so on that same stream, or on a stream that is ordered against it.  Passing NULL selects the
+ *     device's legacy default stream, which HIP orders against every blocking stream — including the
+ *     default stream torch uses — so the NULL context is safe next to default-stream callers without
+ *     manual synchronisation.  STARK_STREAM_PRIVATE asks for a private non-blocking stream instead:
+ *     fastest in isolation, but then the CALLER brackets its own device work with stark_ctx_sync.
  *   - There is NO CPU fallback: without a usable HIP device every compute entry point fails with
  *     STARK_ERR_HIP.
  */
@@ -49,11 +57,18 @@ typedef struct stark_fri_plan stark_fri_plan_t;
 
 /* ---- context / memory ------------------------------------------------------------------------- */
 int32_t stark_version(void);
-/* device: HIP device ordinal.  stream: a hipStream_t to run on (e.g. torch's current stream), or NULL
- * to let the context create its own. */
+/* device: HIP device ordinal.  stream: the hipStream_t to run on (e.g. torch's current stream);
+ * NULL = the legacy default stream; STARK_STREAM_PRIVATE = a private non-blocking stream (see "Stream rule").
+ * (SURVEY.md §8(b) sketched `stark_ctx_create(devices, ndev)`: this build runs one process per GPU, so a
+ * context is one device; the communicator that spans the GPUs is stark_comm_* below.) */
+#define STARK_STREAM_PRIVATE ((void*)(intptr_t)-1)
 int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out);
 int32_t stark_ctx_destroy(stark_ctx_t* ctx);
 int32_t stark_ctx_sync(stark_ctx_t* ctx);
+/* The library keeps released temporaries / layers / tree levels in a per-context cache (no hipMalloc /
+ * hipFree on the hot path).  trim hands the cached blocks back to the driver. */
+int32_t stark_ctx_trim(stark_ctx_t* ctx);
+size_t  stark_ctx_cached_bytes(stark_ctx_t* ctx);
 const char* stark_last_error(stark_ctx_t* ctx);
 int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr);
 int32_t stark_free(stark_ctx_t* ctx, void* dptr);

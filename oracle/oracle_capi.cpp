@@ -205,6 +205,19 @@ int oracle_deep_fri_verify(const uint8_t* bytes, size_t n, const size_t* schedul
     DeepFriProof p; if (!decode_proof(bytes, n, p)) return -1;
     try { return deep_fri_verify(prm, p) ? 1 : 0; } catch (...) { return 0; }
 }
+// Horner evaluation of sum_j c[j] x^j at k points (the O(n)-per-point DEFINITION of polynomial evaluation: pins sampled outputs
+// of the large NTT / LDE / six-step transforms, where the O(n^2) DFT is out of reach).
+int oracle_poly_eval_many(int field, const uint64_t* coeffs, size_t n, const uint64_t* points, size_t k, uint64_t* out) {
+    TRY
+    if (field == 0) {
+        #pragma omp parallel for schedule(dynamic)
+        for (long p = 0; p < (long)k; ++p) { const Fr x = Fr::from_raw(points + 4 * p); Fr acc = Fr::zero(); for (size_t j = n; j-- > 0;) acc = acc * x + Fr::from_raw(coeffs + 4 * j); memcpy(out + 4 * p, acc.l, 32); }
+    } else {
+        #pragma omp parallel for schedule(dynamic)
+        for (long p = 0; p < (long)k; ++p) { const FrBls x = FrBls::from_raw(points + 4 * p); FrBls acc = FrBls::zero(); for (size_t j = n; j-- > 0;) acc = acc * x + FrBls::from_raw(coeffs + 4 * j); memcpy(out + 4 * p, acc.l, 32); }
+    }
+    CATCH }
+
 // deep_fri_proof_size_bytes recomputed from encoded bytes.
 long oracle_proof_size_estimate_from_bytes(const uint8_t* bytes, size_t n) { DeepFriProof p; if (!decode_proof(bytes, n, p)) return -1; return (long)deep_fri_proof_size_bytes(p); }
 

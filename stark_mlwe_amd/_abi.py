@@ -30,6 +30,8 @@ SIGNATURES = {
     "stark_ctx_create": (i32, [i32, vp, vpp]),
     "stark_ctx_destroy": (i32, [vp]),
     "stark_ctx_sync": (i32, [vp]),
+    "stark_ctx_trim": (i32, [vp]),
+    "stark_ctx_cached_bytes": (sz, [vp]),
     "stark_last_error": (C.c_char_p, [vp]),
     "stark_malloc": (i32, [vp, sz, vpp]),
     "stark_free": (i32, [vp, vp]),

@@ -180,17 +180,27 @@ class DeepFriParams:
         self.schedule, self.r, self.seed_z = list(schedule), r, seed_z
 
 
+STREAM_PRIVATE = C.c_void_p(-1)      # STARK_STREAM_PRIVATE: a private non-blocking stream (the caller synchronises around its own device work)
+
+
 class Context:
-    """One context = one GPU = one host thread (include/stark_mlwe.h conventions)."""
+    """One context = one GPU = one host thread (include/stark_mlwe.h conventions).
+
+    `stream`: a hipStream_t handle (e.g. `torch.cuda.current_stream().cuda_stream`), None for the device's legacy default
+    stream (ordered against torch's default stream: safe without manual synchronisation), or STREAM_PRIVATE."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load_library()
         h = C.c_void_p()
+        if isinstance(stream, int):
+            stream = C.c_void_p(stream) if stream else None
         rc = self.lib.stark_ctx_create(device, stream, C.byref(h))
         if rc != 0:
             raise StarkError(rc, "stark_ctx_create failed: no usable HIP device (the product path has no CPU fallback)")
         self.h = h
-        self.stream_handle = (stream.value if isinstance(stream, C.c_void_p) else stream) or 0    # 0: the library made its own stream
+        v = stream.value if isinstance(stream, C.c_void_p) else None
+        self.private_stream = v is not None and v == STREAM_PRIVATE.value
+        self.stream_handle = -1 if self.private_stream else (v or 0)       # 0: the legacy default stream
         self._tparams = None
         self._mparams = {}
 
@@ -207,6 +217,10 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.stark_ctx_sync(self.h))
+
+    def trim(self):
+        """Return the context's cached device blocks to the driver."""
+        self._chk(self.lib.stark_ctx_trim(self.h))
 
     # ---- constants ------------------------------------------------------------------------------
     def poseidon_params_for_width(self, t):

@@ -29,6 +29,44 @@ int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out) {
     *out = ctx->scratch; return STARK_OK;
 }
 
+// ---- caching device allocator (stark_ctx::pool_free) ----------------------------------------------------------
+static inline size_t pool_round(size_t bytes) {
+    if (bytes < 256) return 256;
+    if (bytes <= (1u << 20)) { size_t r = 256; while (r < bytes) r <<= 1; return r; }       // small: powers of two
+    return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);                             // large: whole MiB (layer / level sizes repeat exactly)
+}
+int32_t ctx_alloc(stark_ctx* ctx, size_t bytes, void** out) {
+    const size_t sz = pool_round(bytes);
+    auto it = ctx->pool_free.find(sz);
+    if (it != ctx->pool_free.end() && !it->second.empty()) {
+        void* p = it->second.back(); it->second.pop_back(); ctx->pool_cached_bytes -= sz;
+        ctx->pool_live[p] = sz; *out = p; return STARK_OK;
+    }
+    void* p = nullptr; hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {                                       // out of memory: give the cached blocks back and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->pool_free) { for (void* q : kv.second) (void)hipFree(q); kv.second.clear(); }
+        ctx->pool_cached_bytes = 0;
+        e = hipMalloc(&p, sz);
+        if (e != hipSuccess) { (void)hipGetLastError(); return ctx->fail(STARK_ERR_OOM, "device allocation of " + std::to_string(sz) + " bytes failed"); }
+    }
+    ctx->pool_live[p] = sz; *out = p; return STARK_OK;
+}
+void ctx_release(stark_ctx* ctx, void* p) {
+    if (!p || !ctx) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) { (void)hipFree(p); return; }            // not ours (defensive)
+    const size_t sz = it->second; ctx->pool_live.erase(it);
+    ctx->pool_free[sz].push_back(p); ctx->pool_cached_bytes += sz;
+}
+int32_t ctx_enter(stark_ctx* ctx) {
+    if (!ctx) return STARK_ERR_INVALID_ARG;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) STARK_HIP(ctx, hipSetDevice(ctx->device));
+    return STARK_OK;
+}
+
 int32_t ctx_side_stream(stark_ctx* ctx, hipStream_t* out) {
     if (!ctx->side_stream) { STARK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)); STARK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); }
     *out = ctx->side_stream; return STARK_OK;
@@ -130,7 +168,7 @@ int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr
     return STARK_OK;
 }
 int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out) {
-    DevBuf in, o; STARK_HIP(ctx, in.alloc(fields.size() * sizeof(fr_t))); STARK_HIP(ctx, o.alloc(sizeof(fr_t)));
+    DevBuf in, o; STARK_HIP(ctx, in.alloc(ctx, fields.size() * sizeof(fr_t))); STARK_HIP(ctx, o.alloc(ctx, sizeof(fr_t)));
     if (!fields.empty()) STARK_HIP(ctx, hipMemcpyAsync(in.p, fields.data(), fields.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(tr_hash_dev(ctx, tag, in.fr(), fields.size(), 1, o.fr()));
     STARK_HIP(ctx, hipMemcpyAsync(out, o.p, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -179,9 +217,10 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return STARK_ERR_HIP;   // no device => no product path
     if (hipSetDevice(device) != hipSuccess) return STARK_ERR_HIP;
     stark_ctx* c = new stark_ctx(); c->device = device;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return STARK_ERR_HIP; } c->own_stream = true; }
+    if (stream == STARK_STREAM_PRIVATE) { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return STARK_ERR_HIP; } c->own_stream = true; }
+    else { c->stream = (hipStream_t)stream; c->own_stream = false; }         // NULL = the device's legacy default stream (ordered against torch's default stream and every blocking stream)
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return STARK_ERR_HIP; }
+    stark::ntt_set_attrs();
     // allow the full 160 KiB of LDS per workgroup for the kernels that stage through it
     (void)hipFuncSetAttribute((const void*)k_leaf_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_hash_ds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
@@ -195,6 +234,7 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
 }
 int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (!ctx) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
     stark::ntt_plans_free(ctx);
     if (ctx->tparams) stark_poseidon_params_free(ctx->tparams);
@@ -202,6 +242,10 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     for (auto& kv : ctx->tr_frames) (void)hipFree(kv.second);
     if (ctx->leaf_init) (void)hipFree(ctx->leaf_init);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto& o : ctx->omega_tabs) { (void)hipFree(o.lo); (void)hipFree(o.hi); }
+    for (auto& kv : ctx->pool_free) for (void* q : kv.second) (void)hipFree(q);
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);                 // handles the caller never freed
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0); if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -209,24 +253,35 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx; return STARK_OK;
 }
-int32_t stark_ctx_sync(stark_ctx_t* ctx) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
+int32_t stark_ctx_sync(stark_ctx_t* ctx) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
+int32_t stark_ctx_trim(stark_ctx_t* ctx) {
+    if (!ctx) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->pool_free) { for (void* q : kv.second) (void)hipFree(q); kv.second.clear(); }
+    ctx->pool_cached_bytes = 0; return STARK_OK;
+}
+size_t stark_ctx_cached_bytes(stark_ctx_t* ctx) { return ctx ? ctx->pool_cached_bytes : 0; }
 const char* stark_last_error(stark_ctx_t* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr) { if (!ctx || !dptr) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 32)); return STARK_OK; }
-int32_t stark_free(stark_ctx_t* ctx, void* dptr) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); STARK_HIP(ctx, hipFree(dptr)); return STARK_OK; }
+int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr) { if (!ctx || !dptr) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx)); STARK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 32)); return STARK_OK; }
+int32_t stark_free(stark_ctx_t* ctx, void* dptr) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); STARK_HIP(ctx, hipFree(dptr)); return STARK_OK; }
 int32_t stark_memcpy_h2d(stark_ctx_t* ctx, void* d, const void* s, size_t bytes) {
     if (!ctx) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     STARK_HIP(ctx, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
 int32_t stark_memcpy_d2h(stark_ctx_t* ctx, void* d, const void* s, size_t bytes) {
     if (!ctx) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     STARK_HIP(ctx, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
 int32_t stark_timer_start(stark_ctx_t* ctx) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream)); return STARK_OK; }
 int32_t stark_timer_stop_ms(stark_ctx_t* ctx, float* ms) {
     if (!ctx || !ms) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     STARK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream)); STARK_HIP(ctx, hipEventSynchronize(ctx->ev1)); STARK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1)); return STARK_OK; }
 
 // ---- constants ---------------------------------------------------------------------------------------
 int32_t stark_poseidon_params_upload(stark_ctx_t* ctx, int32_t t, int32_t rf, int32_t rp, const uint64_t* mds, const uint64_t* rc_full, const uint64_t* rc_partial, stark_params_t** out) {
     if (!ctx || !mds || !rc_full || !rc_partial || !out || t < 2 || rf <= 0 || (rf & 1) || rp <= 0) return ctx ? ctx->fail(STARK_ERR_INVALID_ARG, "bad params") : STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     host::PoseidonConsts c; c.t = t; c.rf = rf; c.rp = rp;
     c.mds.resize((size_t)t * t); c.rc_full.resize((size_t)rf * t); c.rc_partial.resize(rp);
     for (size_t i = 0; i < c.mds.size(); ++i) c.mds[i] = load_fr(mds + 4 * i);
@@ -236,11 +291,13 @@ int32_t stark_poseidon_params_upload(stark_ctx_t* ctx, int32_t t, int32_t rf, in
 }
 int32_t stark_poseidon_params_for_width(stark_ctx_t* ctx, int32_t t, stark_params_t** out) {
     if (!ctx || !out) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (host::rp_for_width(t) < 0) return ctx->fail(STARK_ERR_UNSUPPORTED, "unsupported Poseidon width t; supported t in {9,17,33,65,129}");   // poseidon/src/lib.rs:127
     return params_from_consts(ctx, host::consts_for_width(t), out);
 }
 int32_t stark_poseidon_params_t17_seed(stark_ctx_t* ctx, const uint8_t* seed, size_t n, stark_params_t** out) {
     if (!ctx || !out || (!seed && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     return params_from_consts(ctx, host::derive_consts(std::string((const char*)seed, n), 17, 8, 64), out);
 }
 int32_t stark_poseidon_params_export(stark_params_t* p, int32_t* t, int32_t* rf, int32_t* rp, uint64_t* mds, uint64_t* rc_full, uint64_t* rc_partial) {
@@ -256,6 +313,7 @@ int32_t stark_poseidon_params_free(stark_params_t* p) { if (!p) return STARK_ERR
 // ---- Poseidon ----------------------------------------------------------------------------------------
 int32_t stark_poseidon_permute_batch_dev(stark_ctx_t* ctx, stark_params_t* p, uint64_t* states, size_t n) {
     if (!ctx || !p || (!states && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (!n) return STARK_OK;
     const int block = poseidon_block(p->dev.t);
     hipLaunchKernelGGL(k_permute_batch, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), ctx->stream, p->dev, as_fr(states), n);
@@ -263,14 +321,15 @@ int32_t stark_poseidon_permute_batch_dev(stark_ctx_t* ctx, stark_params_t* p, ui
 }
 int32_t stark_poseidon_permute_batch(stark_ctx_t* ctx, stark_params_t* p, uint64_t* states, size_t n) {
     if (!ctx || !p || (!states && n)) return STARK_ERR_INVALID_ARG;
-    size_t bytes = n * p->dev.t * sizeof(fr_t); DevBuf d; STARK_HIP(ctx, d.alloc(bytes));
+    STARK_TRY(ctx_enter(ctx));
+    size_t bytes = n * p->dev.t * sizeof(fr_t); DevBuf d; STARK_HIP(ctx, d.alloc(ctx, bytes));
     STARK_HIP(ctx, hipMemcpyAsync(d.p, states, bytes, hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(stark_poseidon_permute_batch_dev(ctx, p, (uint64_t*)d.p, n));
     STARK_HIP(ctx, hipMemcpyAsync(states, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
 static int32_t hash_stream(stark_ctx_t* ctx, stark_params_t* p, int mode, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, const fr_t& tag, size_t n, uint64_t* out) {
-    DevBuf da, db, dout; STARK_HIP(ctx, da.alloc(n * na * sizeof(fr_t))); STARK_HIP(ctx, db.alloc(n * nb * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n * sizeof(fr_t)));
+    DevBuf da, db, dout; STARK_HIP(ctx, da.alloc(ctx, n * na * sizeof(fr_t))); STARK_HIP(ctx, db.alloc(ctx, n * nb * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(ctx, n * sizeof(fr_t)));
     if (n * na) STARK_HIP(ctx, hipMemcpyAsync(da.p, a, n * na * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     if (n * nb) STARK_HIP(ctx, hipMemcpyAsync(db.p, b, n * nb * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     const int block = poseidon_block(p->dev.t);
@@ -281,64 +340,92 @@ static int32_t hash_stream(stark_ctx_t* ctx, stark_params_t* p, int mode, const 
 }
 int32_t stark_poseidon_hash_with_ds_dynamic(stark_ctx_t* ctx, stark_params_t* p, const uint64_t* ds, size_t nds, const uint64_t* in, size_t cnt, size_t n, uint64_t* out) {
     if (!ctx || !p || !out || (!ds && nds) || (!in && cnt)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (!n) return STARK_OK;
     return hash_stream(ctx, p, 0, ds, nds, in, cnt, host::h_zero(), n, out);
 }
 int32_t stark_poseidon_hash_with_ds(stark_ctx_t* ctx, stark_params_t* p, const uint64_t* in, size_t cnt, const uint64_t* ds_tag, uint64_t* out) {
     if (!ctx || !p || !out || !ds_tag || (!in && cnt)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (p->dev.t != 17) return ctx->fail(STARK_ERR_INVALID_ARG, "hash_with_ds is the fixed t=17 sponge");
     return hash_stream(ctx, p, 1, nullptr, 0, in, cnt, load_fr(ds_tag), 1, out);
 }
-static int32_t launch_hash_ds(stark_ctx_t* ctx, stark_params_t* p, int mode, size_t arity, uint32_t level, uint64_t pos0, uint64_t label,
-                              const fr_t* in0, const fr_t* in1, size_t n_in, fr_t* out) {
-    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
+static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* p, int mode, size_t arity, uint32_t level, uint64_t pos0, uint64_t label,
+                              const fr_t* in0, const fr_t* in1, size_t n_in, fr_t* out, size_t cp_div = 1) {
+    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode; J.cp_div = cp_div ? cp_div : 1;
     J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
     if (!J.n_out) return STARK_OK;
     if (use_pair(p->dev.t) && J.n_out <= 8192) {
         // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
-        if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), ctx->stream, p->dev, J, in0, in1, out);
-        else hipLaunchKernelGGL(k_hash_ds_coop<9>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(9), ctx->stream, p->dev, J, in0, in1, out);
+        if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), st, p->dev, J, in0, in1, out);
+        else hipLaunchKernelGGL(k_hash_ds_coop<9>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(9), st, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     if (use_pair(p->dev.t)) {
-        if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds2<17>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(17), ctx->stream, p->dev, J, in0, in1, out);
-        else hipLaunchKernelGGL(k_hash_ds2<9>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(9), ctx->stream, p->dev, J, in0, in1, out);
+        if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds2<17>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(17), st, p->dev, J, in0, in1, out);
+        else hipLaunchKernelGGL(k_hash_ds2<9>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(9), st, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     const int block = poseidon_block(p->dev.t);
-    hipLaunchKernelGGL(k_hash_ds, dim3((unsigned)((J.n_out + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), ctx->stream, p->dev, J, in0, in1, out);
+    hipLaunchKernelGGL(k_hash_ds, dim3((unsigned)((J.n_out + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), st, p->dev, J, in0, in1, out);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
 int32_t stark_poseidon_hash_ds_batch_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in, size_t n_in, uint64_t* out) {
     if (!ctx || !p || !in || !out || arity == 0) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (host::width_for_arity(arity) != p->dev.t) return ctx->fail(STARK_ERR_INVALID_ARG, "arity incompatible with Poseidon width");
-    return launch_hash_ds(ctx, p, 0, arity, level, pos0, label, as_fr(in), nullptr, n_in, as_fr(out));
+    STARK_TRY(ctx_enter(ctx));
+    return launch_hash_ds(ctx, ctx->stream, p, 0, arity, level, pos0, label, as_fr(in), nullptr, n_in, as_fr(out));
 }
 int32_t stark_poseidon_hash_ds_batch(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in, size_t n_in, uint64_t* out) {
     if (!ctx || !p || !in || !out || arity == 0) return STARK_ERR_INVALID_ARG;
-    size_t n_out = (n_in + arity - 1) / arity; DevBuf di, dout; STARK_HIP(ctx, di.alloc(n_in * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n_out * sizeof(fr_t)));
+    STARK_TRY(ctx_enter(ctx));
+    size_t n_out = (n_in + arity - 1) / arity; DevBuf di, dout; STARK_HIP(ctx, di.alloc(ctx, n_in * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(ctx, n_out * sizeof(fr_t)));
     STARK_HIP(ctx, hipMemcpyAsync(di.p, in, n_in * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(stark_poseidon_hash_ds_batch_dev(ctx, p, arity, level, pos0, label, (const uint64_t*)di.p, n_in, (uint64_t*)dout.p));
     STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, n_out * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
-int32_t stark_leaf_pair_hash_dev(stark_ctx_t* ctx, stark_params_t* tp, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h) {
-    if (!ctx || !tp || (!f && n) || (!h && n) || m == 0) return STARK_ERR_INVALID_ARG;
-    if (tp->dev.t != 17) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf hash uses the t=17 transcript permutation");
+}  // extern "C"
+namespace stark {
+// hash_leaf_pair is the FIXED transcript permutation (fri.rs:39: transcript::default_params()): a caller's handle must hold
+// those very constants, anything else would silently mix two parameter sets (round 0 is folded into the context's template).
+static bool same_consts(const host::PoseidonConsts& a, const host::PoseidonConsts& b) {
+    if (a.t != b.t || a.rf != b.rf || a.rp != b.rp || a.mds.size() != b.mds.size() || a.rc_full.size() != b.rc_full.size() || a.rc_partial.size() != b.rc_partial.size()) return false;
+    for (size_t i = 0; i < a.mds.size(); ++i) if (!fr_eq(a.mds[i], b.mds[i])) return false;
+    for (size_t i = 0; i < a.rc_full.size(); ++i) if (!fr_eq(a.rc_full[i], b.rc_full[i])) return false;
+    for (size_t i = 0; i < a.rc_partial.size(); ++i) if (!fr_eq(a.rc_partial[i], b.rc_partial[i])) return false;
+    return true;
+}
+int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const fr_t* f_next, size_t n, size_t m, fr_t* h) {
     if (!n) return STARK_OK;
+    stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
     fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
     if (use_pair(17)) {
-        hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), ctx->stream, tp->dev, init + 17, as_fr(f), as_fr(f_next), n, m, as_fr(h));
+        hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), st, tp->dev, init + 17, f, f_next, n, m, h);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     const int block = 64;
-    hipLaunchKernelGGL(k_leaf_pair, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(17, block), ctx->stream, tp->dev, init, as_fr(f), as_fr(f_next), n, m, as_fr(h));
+    hipLaunchKernelGGL(k_leaf_pair, dim3((unsigned)((n + block - 1) / block)), dim3(block), poseidon_lds(17, block), st, tp->dev, init, f, f_next, n, m, h);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
+}  // namespace stark
+extern "C" {
+int32_t stark_leaf_pair_hash_dev(stark_ctx_t* ctx, stark_params_t* tp, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h) {
+    if (!ctx || (!f && n) || (!h && n) || m == 0) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    if (tp) {    // NULL = the transcript parameters (the only valid choice); a handle is accepted when it holds the same constants
+        if (tp->dev.t != 17) return ctx->fail(STARK_ERR_INVALID_ARG, "leaf hash uses the t=17 transcript permutation");
+        stark_params* mine = nullptr; STARK_TRY(ctx_transcript_params(ctx, &mine));
+        if (tp != mine && !same_consts(tp->ref, mine->ref)) return ctx->fail(STARK_ERR_INVALID_ARG, "hash_leaf_pair is defined over transcript::default_params(); the handle holds other constants");
+    }
+    return leaf_pair_hash_on(ctx, ctx->stream, as_fr(f), as_fr(f_next), n, m, as_fr(h));
+}
 int32_t stark_leaf_pair_hash(stark_ctx_t* ctx, stark_params_t* tp, const uint64_t* f, const uint64_t* f_next, size_t n, size_t m, uint64_t* h) {
-    if (!ctx || !tp || (!f && n) || (!h && n) || m == 0) return STARK_ERR_INVALID_ARG;
+    if (!ctx || (!f && n) || (!h && n) || m == 0) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     size_t nn = f_next ? (n + m - 1) / m : 0; DevBuf df, dn, dh;
-    STARK_HIP(ctx, df.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, dn.alloc(nn * sizeof(fr_t))); STARK_HIP(ctx, dh.alloc(n * sizeof(fr_t)));
+    STARK_HIP(ctx, df.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, dn.alloc(ctx, nn * sizeof(fr_t))); STARK_HIP(ctx, dh.alloc(ctx, n * sizeof(fr_t)));
     if (n) STARK_HIP(ctx, hipMemcpyAsync(df.p, f, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     if (nn) STARK_HIP(ctx, hipMemcpyAsync(dn.p, f_next, nn * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(stark_leaf_pair_hash_dev(ctx, tp, (const uint64_t*)df.p, f_next ? (const uint64_t*)dn.p : nullptr, n, m, (uint64_t*)dh.p));
@@ -347,12 +434,14 @@ int32_t stark_leaf_pair_hash(stark_ctx_t* ctx, stark_params_t* tp, const uint64_
 }
 int32_t stark_tr_hash_fields_tagged_dev(stark_ctx_t* ctx, stark_params_t* tp, const char* tag, const uint64_t* fields, size_t k, size_t n, uint64_t* out) {
     if (!ctx || !tag || (!fields && k && n) || (!out && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     (void)tp;   // the transcript permutation is fixed (transcript/src/lib.rs:44-46); the handle is accepted for API symmetry
     return tr_hash_dev(ctx, tag, as_fr(fields), k, n, as_fr(out));
 }
 int32_t stark_tr_hash_fields_tagged(stark_ctx_t* ctx, stark_params_t* tp, const char* tag, const uint64_t* fields, size_t k, size_t n, uint64_t* out) {
     if (!ctx || !tag || (!fields && k && n) || (!out && n)) return STARK_ERR_INVALID_ARG;
-    DevBuf di, dout; STARK_HIP(ctx, di.alloc(n * k * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n * sizeof(fr_t)));
+    STARK_TRY(ctx_enter(ctx));
+    DevBuf di, dout; STARK_HIP(ctx, di.alloc(ctx, n * k * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(ctx, n * sizeof(fr_t)));
     if (n * k) STARK_HIP(ctx, hipMemcpyAsync(di.p, fields, n * k * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(stark_tr_hash_fields_tagged_dev(ctx, tp, tag, (const uint64_t*)di.p, k, n, (uint64_t*)dout.p));
     if (n) STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -360,36 +449,49 @@ int32_t stark_tr_hash_fields_tagged(stark_ctx_t* ctx, stark_params_t* tp, const 
 }
 
 // ---- Merkle ------------------------------------------------------------------------------------------
-int32_t stark_merkle_build_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t label, const uint64_t* leaves, size_t n, int32_t pairs, const uint64_t* cp,
-                               uint64_t first_pos, uint32_t level0, int32_t stop_at_len, stark_tree_t** out) {
-    if (!ctx || !p || !leaves || !out || arity == 0 || (pairs && !cp)) return ctx ? ctx->fail(STARK_ERR_INVALID_ARG, "bad merkle args") : STARK_ERR_INVALID_ARG;
+}  // extern "C"
+namespace stark {
+// MerkleTree::new / new_pairs on `st`.  pairs: leaves are (f_i, cp[i / cp_div]) pairs (cp == nullptr: zeros).  adopt: `leaves` is a
+// pooled block (ctx_alloc) whose ownership moves into the tree as level 0 (no copy); otherwise level 0 is a copy.
+int32_t merkle_build_on(stark_ctx* ctx, hipStream_t st, stark_params* p, size_t arity, uint64_t label, const fr_t* leaves, size_t n, int pairs, const fr_t* cp, size_t cp_div,
+                        uint64_t first_pos, uint32_t level0, size_t stop_at_len, bool adopt, stark_tree** out) {
     if (n == 0) return ctx->fail(STARK_ERR_INVALID_ARG, "no leaves");                                                 // merkle/src/lib.rs:148
     if (host::width_for_arity(arity) != p->dev.t) return ctx->fail(STARK_ERR_INVALID_ARG, "arity incompatible with Poseidon width");   // :155-161
     if (arity == 1 && n > 1) return ctx->fail(STARK_ERR_UNSUPPORTED, "arity 1 with more than one leaf never terminates in the reference");
     stark_tree* T = new stark_tree(); T->ctx = ctx; T->p = p; T->arity = arity; T->label = label;
     auto bail = [&](int32_t rc) { delete T; return rc; };
     fr_t* l0 = nullptr;
-    if (hipMalloc((void**)&l0, n * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "merkle level 0"));
+    if (adopt && !pairs) l0 = const_cast<fr_t*>(leaves);
+    else { void* q = nullptr; int32_t rc = ctx_alloc(ctx, n * sizeof(fr_t), &q); if (rc) return bail(rc); l0 = (fr_t*)q; }
     T->levels.push_back(l0); T->lens.push_back(n); T->owned.push_back(1);
-    if (pairs) { int32_t rc = launch_hash_ds(ctx, p, 1, arity, 0xFFFFFFFFu, first_pos, label, as_fr(leaves), as_fr(cp), n, l0); if (rc) return bail(rc); }
-    else if (hipMemcpyAsync(l0, leaves, n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "copy leaves"));
-    uint32_t level = level0; uint64_t pos = first_pos; size_t stop = stop_at_len > 0 ? (size_t)stop_at_len : 1;
+    if (pairs) { int32_t rc = launch_hash_ds(ctx, st, p, 1, arity, 0xFFFFFFFFu, first_pos, label, leaves, cp, n, l0, cp_div); if (rc) return bail(rc); }
+    else if (!adopt && hipMemcpyAsync(l0, leaves, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "copy leaves"));
+    uint32_t level = level0; uint64_t pos = first_pos; size_t stop = stop_at_len > 0 ? stop_at_len : 1;
     while (T->lens.back() > stop) {
         size_t len = T->lens.back(), nn = (len + arity - 1) / arity;
         if (pos % arity) return bail(ctx->fail(STARK_ERR_INVALID_ARG, "shard offset not aligned to the arity"));
         pos /= arity;
-        fr_t* nx = nullptr; if (hipMalloc((void**)&nx, nn * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "merkle level"));
-        T->levels.push_back(nx); T->lens.push_back(nn); T->owned.push_back(1);
-        int32_t rc = launch_hash_ds(ctx, p, 0, arity, level, pos, label, T->levels[T->levels.size() - 2], nullptr, len, nx); if (rc) return bail(rc);
+        void* nx = nullptr; { int32_t rc = ctx_alloc(ctx, nn * sizeof(fr_t), &nx); if (rc) return bail(rc); }
+        T->levels.push_back((fr_t*)nx); T->lens.push_back(nn); T->owned.push_back(1);
+        int32_t rc = launch_hash_ds(ctx, st, p, 0, arity, level, pos, label, T->levels[T->levels.size() - 2], nullptr, len, (fr_t*)nx); if (rc) return bail(rc);
         level += 1;
     }
     *out = T; return STARK_OK;
 }
+}  // namespace stark
+extern "C" {
+int32_t stark_merkle_build_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t label, const uint64_t* leaves, size_t n, int32_t pairs, const uint64_t* cp,
+                               uint64_t first_pos, uint32_t level0, int32_t stop_at_len, stark_tree_t** out) {
+    if (!ctx || !p || !leaves || !out || arity == 0 || (pairs && !cp)) return ctx ? ctx->fail(STARK_ERR_INVALID_ARG, "bad merkle args") : STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    return merkle_build_on(ctx, ctx->stream, p, arity, label, as_fr(leaves), n, pairs, as_fr(cp), 1, first_pos, level0, stop_at_len > 0 ? (size_t)stop_at_len : 0, false, out);
+}
 int32_t stark_merkle_build(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint64_t label, const uint64_t* leaves, size_t n, int32_t pairs, const uint64_t* cp, stark_tree_t** out) {
     if (!ctx || !p || !leaves || !out || (pairs && !cp)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (n == 0) return ctx->fail(STARK_ERR_INVALID_ARG, "no leaves");
-    DevBuf dl, dc; STARK_HIP(ctx, dl.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(dl.p, leaves, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
-    if (pairs) { STARK_HIP(ctx, dc.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(dc.p, cp, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
+    DevBuf dl, dc; STARK_HIP(ctx, dl.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(dl.p, leaves, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    if (pairs) { STARK_HIP(ctx, dc.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(dc.p, cp, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
     STARK_TRY(stark_merkle_build_dev(ctx, p, arity, label, (const uint64_t*)dl.p, n, pairs, pairs ? (const uint64_t*)dc.p : nullptr, 0, 0, 0, out));
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
@@ -398,7 +500,7 @@ size_t stark_merkle_level_len(stark_tree_t* t, int32_t lvl) { return (t && lvl >
 const uint64_t* stark_merkle_level_dev(stark_tree_t* t, int32_t lvl) { return (t && lvl >= 0 && (size_t)lvl < t->levels.size()) ? (const uint64_t*)t->levels[lvl] : nullptr; }
 int32_t stark_merkle_level(stark_tree_t* t, int32_t lvl, uint64_t* out) {
     if (!t || !out || lvl < 0 || (size_t)lvl >= t->levels.size()) return STARK_ERR_INVALID_ARG;
-    stark_ctx* ctx = t->ctx;
+    stark_ctx* ctx = t->ctx; STARK_TRY(ctx_enter(ctx));
     STARK_HIP(ctx, hipMemcpyAsync(out, t->levels[lvl], t->lens[lvl] * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
 int32_t stark_merkle_root(stark_tree_t* t, uint64_t* out4) {
@@ -409,15 +511,16 @@ int32_t stark_merkle_root(stark_tree_t* t, uint64_t* out4) {
 int32_t stark_merkle_gather(stark_tree_t* t, int32_t lvl, const size_t* idx, size_t k, uint64_t* out) {
     if (!t || (!idx && k) || (!out && k) || lvl < 0 || (size_t)lvl >= t->levels.size()) return STARK_ERR_INVALID_ARG;
     stark_ctx* ctx = t->ctx; if (!k) return STARK_OK;
+    STARK_TRY(ctx_enter(ctx));
     for (size_t i = 0; i < k; ++i) if (idx[i] >= t->lens[lvl]) return ctx->fail(STARK_ERR_INVALID_ARG, "gather index out of range");
-    DevBuf di, dout; STARK_HIP(ctx, di.alloc(k * 8)); STARK_HIP(ctx, dout.alloc(k * sizeof(fr_t)));
+    DevBuf di, dout; STARK_HIP(ctx, di.alloc(ctx, k * 8)); STARK_HIP(ctx, dout.alloc(ctx, k * sizeof(fr_t)));
     std::vector<uint64_t> ix(idx, idx + k);
     STARK_HIP(ctx, hipMemcpyAsync(di.p, ix.data(), k * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream, t->levels[lvl], (const uint64_t*)di.p, (uint64_t)k, dout.fr());
     STARK_HIP(ctx, hipGetLastError());
     STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, k * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
-int32_t stark_merkle_free(stark_tree_t* t) { if (!t) return STARK_ERR_INVALID_ARG; (void)hipStreamSynchronize(t->ctx->stream); delete t; return STARK_OK; }
+int32_t stark_merkle_free(stark_tree_t* t) { if (!t) return STARK_ERR_INVALID_ARG; delete t; return STARK_OK; }   // levels go back to the context's pool (stream-ordered reuse: no device sync)
 
 }  // extern "C"
 

@@ -12,56 +12,77 @@ using namespace stark;
 struct stark_fri_state {
     stark_ctx* ctx = nullptr;
     std::vector<size_t> schedule;
-    std::vector<fr_t*> f; std::vector<size_t> n;           // L+1 layers (device)
+    std::vector<fr_t*> f; std::vector<size_t> n;           // L+1 layers (device, pooled)
     std::vector<fr_t> z;                                    // L fold challenges
-    std::vector<stark_tree*> trees; std::vector<char> hashed; std::vector<size_t> arity; std::vector<fr_t> roots;
-    ~stark_fri_state() { for (auto p : f) if (p) (void)hipFree(p); for (auto t : trees) if (t) stark_merkle_free(t); }
+    std::vector<stark_tree*> trees; std::vector<char> hashed; std::vector<size_t> arity;
+    std::vector<fr_t> roots;                                // fetched on first use (one download + one sync for all L+1)
+    ~stark_fri_state() { for (auto p : f) if (p) ctx_release(ctx, p); for (auto t : trees) if (t) stark_merkle_free(t); }
 };
 struct stark_proof { std::vector<uint8_t> bytes; size_t size_estimate = 0; double ms[3] = {0, 0, 0}; };
 
 static inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 static inline int ilog2(size_t x) { return ilog2_ceil(x); }
 
-// z^0..z^(m-1) on the device (m <= a few hundred: host powers, one small upload).
-static int32_t upload_zpows(stark_ctx* ctx, const fr_t& z, size_t m, DevBuf& d) {
-    std::vector<fr_t> zp(m); fr_t acc = host::h_one(); for (size_t t = 0; t < m; ++t) { zp[t] = acc; acc = host::h_mul(acc, z); }   // fri.rs:91-93
-    STARK_HIP(ctx, d.alloc(m * sizeof(fr_t)));
-    STARK_HIP(ctx, hipMemcpyAsync(d.p, zp.data(), m * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
-    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // zp is a local: finish the copy before it goes away
+// fold on `st` with the z-power table zp (m entries, device)
+static int32_t fold_launch(stark_ctx* ctx, hipStream_t st, const fr_t* f, size_t n, const fr_t* zp, size_t m, fr_t* out) {
+    if (is_pow2(m)) {
+        int log_m = ilog2(m), log_g = std::min(log_m, 4);
+        uint64_t lanes = (uint64_t)n >> (log_m - log_g);
+        hipLaunchKernelGGL(k_fri_fold_pow2<PallasFr>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, f, (uint64_t)n, zp, log_m, log_g, out);
+    } else {
+        uint64_t no = n / m;
+        hipLaunchKernelGGL(k_fri_fold_any<PallasFr>, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, f, no, zp, (uint64_t)m, out);
+    }
+    STARK_HIP(ctx, hipGetLastError());
     return STARK_OK;
+}
+// z^0..z^(m-1) (fri.rs:91-93) computed ON the device into a pooled table: no host round trip, nothing to keep alive on the host.
+static int32_t zpows_launch(stark_ctx* ctx, hipStream_t st, const fr_t& z, size_t m, fr_t* zp) {
+    hipLaunchKernelGGL(k_zpows<PallasFr>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, z, (uint64_t)m, zp);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
 static int32_t fold_dev(stark_ctx* ctx, const fr_t* f, size_t n, const fr_t& z, size_t m, fr_t* out) {
     if (m < 2) return ctx->fail(STARK_ERR_INVALID_ARG, "m >= 2");                                        // fri.rs:86
     if (n % m) return ctx->fail(STARK_ERR_INVALID_ARG, "layer size must be divisible by m");             // fri.rs:87
     if (!n) return STARK_OK;
-    DevBuf zp; STARK_TRY(upload_zpows(ctx, z, m, zp));
-    if (is_pow2(m)) {
-        int log_m = ilog2(m), log_g = std::min(log_m, 4);
-        uint64_t lanes = (uint64_t)n >> (log_m - log_g);
-        hipLaunchKernelGGL(k_fri_fold_pow2<PallasFr>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, f, (uint64_t)n, (const fr_t*)zp.fr(), log_m, log_g, out);
-    } else {
-        uint64_t no = n / m;
-        hipLaunchKernelGGL(k_fri_fold_any<PallasFr>, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, ctx->stream, f, no, (const fr_t*)zp.fr(), (uint64_t)m, out);
-    }
-    STARK_HIP(ctx, hipGetLastError());
-    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // zp freed on return
-    return STARK_OK;
+    DevBuf zp; STARK_HIP(ctx, zp.alloc(ctx, m * sizeof(fr_t)));
+    STARK_TRY(zpows_launch(ctx, ctx->stream, z, m, zp.fr()));
+    return fold_launch(ctx, ctx->stream, f, n, zp.fr(), m, out);     // zp returns to the pool: its next user is ordered behind this fold on the same stream
 }
 
-// fri_sample_z_ell (fri.rs:59-82): transcript hash on the device, ChaCha12 + candidate test on the host.
+// fri_sample_z_ell (fri.rs:59-82): transcript hash on the device, ChaCha12 + candidate test on the host.  The value depends
+// only on (seed_z, level, domain_size) (fri.rs:250), so it is computed once per context and key.
 static int32_t sample_z(stark_ctx* ctx, uint64_t seed_z, size_t level, size_t domain_size, fr_t* z) {
+    const stark_ctx::ZKey key{seed_z, level, domain_size};
+    auto it = ctx->z_cache.find(key);
+    if (it != ctx->z_cache.end()) { *z = it->second; return STARK_OK; }
     fr_t fused; STARK_TRY(tr_hash_host1(ctx, "FRI/z/l", {host::h_u64(seed_z), host::h_u64(level), host::h_u64(domain_size)}, &fused));
     uint8_t seed[32]; host::h_to_bytes_le(fused, seed);
     host::ChaCha12Rng rng(seed);
     const fr_t one = host::h_one();
     for (size_t tries = 0;;) {
         fr_t cand = host::h_u64(rng.next_u64());
-        if (!fr_is_zero(cand) && !fr_eq(fr_pow_u64<PallasFr>(cand, domain_size), one)) { *z = cand; return STARK_OK; }
+        if (!fr_is_zero(cand) && !fr_eq(fr_pow_u64<PallasFr>(cand, domain_size), one)) { *z = cand; break; }
         if (++tries >= 1000) {
             fr_t fb = host::h_u64(seed_z + (uint64_t)level + 7);
-            *z = !fr_eq(fr_pow_u64<PallasFr>(fb, domain_size), one) ? fb : host::h_u64(11); return STARK_OK;
+            *z = !fr_eq(fr_pow_u64<PallasFr>(fb, domain_size), one) ? fb : host::h_u64(11); break;
         }
     }
+    ctx->z_cache[key] = *z; return STARK_OK;
+}
+
+// All L+1 roots with one download and one synchronisation (the query phase needs them on the host; a caller that only builds
+// the commitments never pays for it).
+static int32_t state_roots(stark_fri_state* S) {
+    if (!S->roots.empty()) return STARK_OK;
+    stark_ctx* ctx = S->ctx; std::vector<fr_t> r(S->trees.size());
+    for (size_t l = 0; l < S->trees.size(); ++l) {
+        stark_tree* T = S->trees[l];
+        if (T->lens.back() != 1) return ctx->fail(STARK_ERR_INVALID_ARG, "partial (sharded) tree has no root");
+        STARK_HIP(ctx, hipMemcpyAsync(&r[l], T->levels.back(), sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S->roots = r; return STARK_OK;
 }
 
 static int32_t fri_build_impl(stark_ctx* ctx, const fr_t* f0_dev, size_t n0, const size_t* schedule, size_t L, uint64_t seed_z, stark_fri_state** out) {
@@ -69,62 +90,74 @@ static int32_t fri_build_impl(stark_ctx* ctx, const fr_t* f0_dev, size_t n0, con
     { size_t n = n0; for (size_t l = 0; l < L; ++l) { if (schedule[l] < 2 || n % schedule[l]) return ctx->fail(STARK_ERR_INVALID_ARG, "schedule not dividing domain size"); n /= schedule[l]; } }   // fri.rs:150
     stark_fri_state* S = new stark_fri_state(); S->ctx = ctx; S->schedule.assign(schedule, schedule + L);
     auto bail = [&](int32_t rc) { delete S; return rc; };
-    stark_params* tp = nullptr; { int32_t rc = ctx_transcript_params(ctx, &tp); if (rc) return bail(rc); }
-    // layer 0 copy + folds back to back (the challenges do not depend on any commitment: fri.rs:250)
-    fr_t* cur = nullptr; if (hipMalloc((void**)&cur, n0 * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "layer 0"));
-    S->f.push_back(cur); S->n.push_back(n0);
-    if (hipMemcpyAsync(cur, f0_dev, n0 * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "copy f0"));
-    for (size_t l = 0; l < L; ++l) {
-        fr_t z; { int32_t rc = sample_z(ctx, seed_z, l, S->n[l], &z); if (rc) return bail(rc); }
-        S->z.push_back(z);
-        size_t nn = S->n[l] / schedule[l]; fr_t* nx = nullptr;
-        if (hipMalloc((void**)&nx, nn * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "fold layer"));
-        S->f.push_back(nx); S->n.push_back(nn);
-        int32_t rc = fold_dev(ctx, S->f[l], S->n[l], z, schedule[l], nx); if (rc) return bail(rc);
+    // Everything that may upload constants (and synchronise doing so) happens BEFORE any stream is forked: transcript
+    // parameters, the leaf template, the Merkle parameters of every layer, the challenges.  After the first call these are all cached.
+    S->n.push_back(n0); for (size_t l = 0; l < L; ++l) S->n.push_back(S->n[l] / schedule[l]);
+    S->arity.assign(L + 1, 0); S->hashed.assign(L + 1, 0); S->trees.assign(L + 1, nullptr);
+    std::vector<stark_params*> mps(L + 1, nullptr);
+    { stark_params* tp = nullptr; int32_t rc = ctx_transcript_params(ctx, &tp); if (rc) return bail(rc); }
+    for (size_t l = 0; l <= L; ++l) {
+        const size_t m_l = l < L ? schedule[l] : 1;
+        S->arity[l] = pick_arity_for_layer(S->n[l], m_l); S->hashed[l] = hashed_arity(S->arity[l]) ? 1 : 0;
+        int32_t rc = ctx_merkle_params(ctx, host::width_for_arity(S->arity[l]), &mps[l]); if (rc) return bail(rc);     // MerkleChannelCfg::new(arity), fri.rs:277
     }
-    // Commitments of all L+1 layers (independent jobs).  Layer 0 is ~94 % of the hashing and fills the GPU; the later layers
-    // are small and mostly LATENCY-bound (tree tops: one dependent permutation per level), so they are enqueued first on a
-    // side stream and run underneath layer 0 instead of after it.  Temporaries stay alive until both streams have drained
-    // (a hipFree in between would synchronise the device and serialise the two again).
+    size_t zp_total = 0;
+    for (size_t l = 0; l < L; ++l) { fr_t z; int32_t rc = sample_z(ctx, seed_z, l, S->n[l], &z); if (rc) return bail(rc); S->z.push_back(z); zp_total += schedule[l]; }
     hipStream_t main_stream = ctx->stream, side = nullptr;
     { int32_t rc = ctx_side_stream(ctx, &side); if (rc) return bail(rc); }
+    // layer 0 copy + folds back to back (the challenges do not depend on any commitment: fri.rs:250)
+    for (size_t l = 0; l <= L; ++l) { void* q = nullptr; int32_t rc = ctx_alloc(ctx, S->n[l] * sizeof(fr_t), &q); S->f.push_back((fr_t*)q); if (rc) return bail(rc); }
+    if (hipMemcpyAsync(S->f[0], f0_dev, n0 * sizeof(fr_t), hipMemcpyDeviceToDevice, main_stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "copy f0"));
+    DevBuf zp; if (L && zp.alloc(ctx, zp_total * sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "z powers"));
+    { size_t off = 0;
+      for (size_t l = 0; l < L; ++l) {
+          int32_t rc = zpows_launch(ctx, main_stream, S->z[l], schedule[l], zp.fr() + off); if (rc) return bail(rc);
+          rc = fold_launch(ctx, main_stream, S->f[l], S->n[l], zp.fr() + off, schedule[l], S->f[l + 1]); if (rc) return bail(rc);
+          off += schedule[l];
+      } }
+    // Commitments of all L+1 layers (independent jobs).  Layer 0 is ~94 % of the hashing and fills the GPU; the later layers
+    // are small and mostly LATENCY-bound (tree tops: one dependent permutation per level), so they go to a side stream and run
+    // underneath layer 0 instead of after it.  The streams are passed explicitly; the side stream is forked from and joined back
+    // into the main one with events, so nothing here synchronises the host.
     if (hipEventRecord(ctx->ev_fork, main_stream) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_fork, 0) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "fork"));
-    std::vector<DevBuf> keep(2 * (L + 1) + 1);
-    size_t nkeep = 0;
-    S->trees.assign(L + 1, nullptr); S->hashed.assign(L + 1, 0); S->arity.assign(L + 1, 0);
-    auto commit_layer = [&](size_t l) -> int32_t {
-        size_t n = S->n[l], m_l = l < L ? schedule[l] : 1, arity = pick_arity_for_layer(n, m_l); bool hashed = hashed_arity(arity);
-        stark_params* mp = nullptr; STARK_TRY(ctx_merkle_params(ctx, host::width_for_arity(arity), &mp));    // MerkleChannelCfg::new(arity), fri.rs:277
+    auto commit_layer = [&](size_t l, hipStream_t st) -> int32_t {
+        const size_t n = S->n[l], m_l = l < L ? schedule[l] : 1, arity = S->arity[l];
         stark_tree* T = nullptr;
-        if (hashed) {
-            DevBuf& h = keep[nkeep++]; if (h.alloc(n * sizeof(fr_t)) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "leaf digests");
-            STARK_TRY(stark_leaf_pair_hash_dev(ctx, tp, (const uint64_t*)S->f[l], l < L ? (const uint64_t*)S->f[l + 1] : nullptr, n, m_l, (uint64_t*)h.p));     // fri.rs:283 (s = f_{l+1}[i/m] view)
-            STARK_TRY(stark_merkle_build_dev(ctx, mp, arity, (uint64_t)l, (const uint64_t*)h.p, n, 0, nullptr, 0, 0, 0, &T));
+        if (S->hashed[l]) {
+            void* h = nullptr; STARK_TRY(ctx_alloc(ctx, n * sizeof(fr_t), &h));
+            int32_t rc = leaf_pair_hash_on(ctx, st, S->f[l], l < L ? S->f[l + 1] : nullptr, n, m_l, (fr_t*)h);        // fri.rs:283 (s = f_{l+1}[i/m] view)
+            if (rc == STARK_OK) rc = merkle_build_on(ctx, st, mps[l], arity, (uint64_t)l, (const fr_t*)h, n, 0, nullptr, 1, 0, 0, 0, /*adopt=*/true, &T);   // the digests become level 0
+            if (rc) { if (!T) ctx_release(ctx, h); return rc; }
         } else {
-            // commit_pairs(f_l, s_l) (fri.rs:289): s_l is the m-fold replication of f_{l+1}, or zeros on the last layer (fri.rs:266)
-            DevBuf& sl = keep[nkeep++]; if (sl.alloc(n * sizeof(fr_t)) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "s layer");
-            if (l < L) {
-                std::vector<uint64_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i / m_l;
-                DevBuf& di = keep[nkeep++]; if (di.alloc(n * 8) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "s idx");
-                if (hipMemcpyAsync(di.p, idx.data(), n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return ctx->fail(STARK_ERR_HIP, "copy idx");
-                if (hipStreamSynchronize(ctx->stream) != hipSuccess) return ctx->fail(STARK_ERR_HIP, "idx upload");     // idx is a host temporary
-                hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t*)S->f[l + 1], (const uint64_t*)di.p, (uint64_t)n, sl.fr());
-            } else if (hipMemsetAsync(sl.p, 0, n * sizeof(fr_t), ctx->stream) != hipSuccess) return ctx->fail(STARK_ERR_HIP, "memset");
-            STARK_TRY(stark_merkle_build_dev(ctx, mp, arity, (uint64_t)l, (const uint64_t*)S->f[l], n, 1, (const uint64_t*)sl.p, 0, 0, 0, &T));
+            // commit_pairs(f_l, s_l) (fri.rs:289): s_l is the m-fold replication of f_{l+1} (read as the view f_{l+1}[i / m]), or zeros on the last layer (fri.rs:266)
+            STARK_TRY(merkle_build_on(ctx, st, mps[l], arity, (uint64_t)l, S->f[l], n, 1, l < L ? S->f[l + 1] : nullptr, m_l, 0, 0, 0, false, &T));
         }
-        S->trees[l] = T; S->hashed[l] = hashed ? 1 : 0; S->arity[l] = arity;
+        S->trees[l] = T;
         return STARK_OK;
     };
     int32_t crc = STARK_OK;
-    ctx->stream = side;
-    for (size_t l = L; l >= 1 && crc == STARK_OK; --l) crc = commit_layer(l);
-    ctx->stream = main_stream;
-    if (crc == STARK_OK) crc = commit_layer(0);
-    const bool drained = hipStreamSynchronize(side) == hipSuccess && hipStreamSynchronize(main_stream) == hipSuccess;
-    if (crc != STARK_OK) return bail(crc);
-    if (!drained) return bail(ctx->fail(STARK_ERR_HIP, "sync"));
-    for (size_t l = 0; l <= L; ++l) { fr_t root; int32_t rc = stark_merkle_root(S->trees[l], (uint64_t*)&root); if (rc) return bail(rc); S->roots.push_back(root); }
+    for (size_t l = L; l >= 1 && crc == STARK_OK; --l) crc = commit_layer(l, side);
+    if (crc == STARK_OK) crc = commit_layer(0, main_stream);
+    // join: the main stream continues only after the side stream's commitments
+    if (hipEventRecord(ctx->ev_fork, side) != hipSuccess || hipStreamWaitEvent(main_stream, ctx->ev_fork, 0) != hipSuccess) { (void)hipStreamSynchronize(side); return bail(ctx->fail(STARK_ERR_HIP, "join")); }
+    if (crc != STARK_OK) { (void)hipStreamSynchronize(side); (void)hipStreamSynchronize(main_stream); return bail(crc); }
     *out = S; return STARK_OK;
+}
+
+// Two-level power table of a domain generator, cached per (generator, size) — the reference's DomainH (deep_ali/src/lib.rs:109-125).
+static int32_t omega_table(stark_ctx* ctx, const fr_t& omega, size_t n_global, PowTable* out) {
+    int bits = ilog2(n_global); if (bits < 1) bits = 1;
+    for (auto& o : ctx->omega_tabs) if (o.bits == bits && fr_eq(o.omega, omega)) { *out = PowTable{o.lo, o.hi, o.lo_bits}; return STARK_OK; }
+    const int lo_bits = (bits + 1) / 2, hi_bits = bits - lo_bits + 1;
+    fr_t *lo = nullptr, *hi = nullptr;
+    STARK_HIP(ctx, hipMalloc((void**)&lo, ((size_t)1 << lo_bits) * sizeof(fr_t)));
+    if (hipMalloc((void**)&hi, ((size_t)1 << hi_bits) * sizeof(fr_t)) != hipSuccess) { (void)hipFree(lo); return ctx->fail(STARK_ERR_OOM, "omega table"); }
+    const uint64_t tot = (1ull << lo_bits) + (1ull << hi_bits);
+    hipLaunchKernelGGL(k_fill_pow_table<PallasFr>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lo, hi, lo_bits, hi_bits, omega, host::h_one());
+    STARK_HIP(ctx, hipGetLastError());
+    if (ctx->omega_tabs.size() >= 16) { STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->omega_tabs[0].lo); (void)hipFree(ctx->omega_tabs[0].hi); ctx->omega_tabs.erase(ctx->omega_tabs.begin()); }
+    ctx->omega_tabs.push_back({bits, omega, lo, hi, lo_bits});
+    *out = PowTable{lo, hi, lo_bits}; return STARK_OK;
 }
 
 // deep_ali_merge_evals_blinded on device pointers (deep_ali/src/lib.rs:60-105).
@@ -135,27 +168,21 @@ static int32_t ali_merge_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, 
     if (!n_global) n_global = n;
     if (n_global <= 1 || !n || j0 + n > n_global) return ctx->fail(STARK_ERR_INVALID_ARG, "n > 1");                        // lib.rs:71
     if (fr_eq(fr_pow_u64<PallasFr>(z, n_global), host::h_one())) return ctx->fail(STARK_ERR_INVALID_ARG, "z must be outside H");   // lib.rs:78
-    // power table of omega: two levels of 2^ceil(b/2) entries, b = bits of n_global
-    int bits = ilog2(n_global); if (bits < 1) bits = 1; int lo_bits = (bits + 1) / 2, hi_bits = bits - lo_bits + 1;
-    DevBuf tlo, thi; STARK_HIP(ctx, tlo.alloc(((size_t)1 << lo_bits) * sizeof(fr_t))); STARK_HIP(ctx, thi.alloc(((size_t)1 << hi_bits) * sizeof(fr_t)));
-    { uint64_t tot = (1ull << lo_bits) + (1ull << hi_bits);
-      hipLaunchKernelGGL(k_fill_pow_table<PallasFr>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tlo.fr(), thi.fr(), lo_bits, hi_bits, omega, host::h_one());
-      STARK_HIP(ctx, hipGetLastError()); }
-    PowTable wp{tlo.fr(), thi.fr(), lo_bits};
+    PowTable wp; STARK_TRY(omega_table(ctx, omega, n_global, &wp));
     const unsigned block = 256; uint64_t lanes = (n + ALI_K - 1) / ALI_K; unsigned grid = (unsigned)((lanes + block - 1) / block);
     const uint64_t T = (uint64_t)grid * block;
     fr_t w_step = fr_pow_u64<PallasFr>(omega, T);
-    DevBuf sums; STARK_HIP(ctx, sums.alloc((size_t)grid * sizeof(fr_t)));
+    DevBuf sums; if (c_star_host) STARK_HIP(ctx, sums.alloc(ctx, (size_t)grid * sizeof(fr_t)));
     hipLaunchKernelGGL(k_ali_merge<PallasFr>, dim3(grid), dim3(block), 0, ctx->stream, a, s, e, t, r_opt, beta, wp, w_step, fr_inv<PallasFr>(w_step), z, (uint64_t)n, j0, f0, c_star_host ? sums.fr() : (fr_t*)nullptr);
     STARK_HIP(ctx, hipGetLastError());
     if (c_star_host) {
         // c* = phi(z)/Z_H(z) = (1/n) * sum_j phi_j w^j/(z - w^j)   (lib.rs:44 and :94); block partials are reduced on the device
-        DevBuf tot; STARK_HIP(ctx, tot.alloc(sizeof(fr_t)));
+        DevBuf tot; STARK_HIP(ctx, tot.alloc(ctx, sizeof(fr_t)));
         hipLaunchKernelGGL(k_sum_single_block<PallasFr>, dim3(1), dim3(256), 0, ctx->stream, (const fr_t*)sums.fr(), (uint64_t)grid, partial_only ? host::h_one() : fr_inv<PallasFr>(host::h_u64(n_global)), tot.fr());
         STARK_HIP(ctx, hipGetLastError());
         STARK_HIP(ctx, hipMemcpyAsync(c_star_host, tot.p, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+        STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the caller reads *c_star_host on return
     }
-    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return STARK_OK;
 }
 
@@ -178,7 +205,7 @@ static int32_t ali_sample_z_beta(stark_ctx* ctx, const char* tag, size_t n0, con
 static int32_t build_f0_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, const fr_t* e, const fr_t* t, size_t n0, fr_t* f0, fr_t* aux7) {
     if (n0 <= 1) return ctx->fail(STARK_ERR_INVALID_ARG, "n0 > 1");
     // four serial column sponges (fri.rs:551-554): one lane per column, inherently sequential in n0
-    DevBuf dig; STARK_HIP(ctx, dig.alloc(4 * sizeof(fr_t)));
+    DevBuf dig; STARK_HIP(ctx, dig.alloc(ctx, 4 * sizeof(fr_t)));
     const fr_t* cols[4] = {a, s, e, t}; const char* tags[4] = {"ALI/A", "ALI/S", "ALI/E", "ALI/T"};
     STARK_TRY(tr_hash_columns4_dev(ctx, tags, cols, n0, dig.fr()));           // the chains are independent: one launch, four concurrent blocks
     fr_t h[5]; STARK_HIP(ctx, hipMemcpyAsync(h, dig.p, 4 * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -199,7 +226,7 @@ struct LocalSource : FriSource {
         outv.resize(idx.size()); if (idx.empty()) return STARK_OK;
         if (l >= S->f.size()) return ctx->fail(STARK_ERR_INVALID_ARG, "layer out of range");
         for (size_t i : idx) if (i >= S->n[l]) return ctx->fail(STARK_ERR_INVALID_ARG, "layer index out of range");
-        DevBuf di, dout; STARK_HIP(ctx, di.alloc(idx.size() * 8)); STARK_HIP(ctx, dout.alloc(idx.size() * sizeof(fr_t)));
+        DevBuf di, dout; STARK_HIP(ctx, di.alloc(ctx, idx.size() * 8)); STARK_HIP(ctx, dout.alloc(ctx, idx.size() * sizeof(fr_t)));
         std::vector<uint64_t> ix(idx.begin(), idx.end());
         STARK_HIP(ctx, hipMemcpyAsync(di.p, ix.data(), ix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_gather, dim3((unsigned)((ix.size() + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t*)S->f[l], (const uint64_t*)di.p, (uint64_t)ix.size(), dout.fr());
@@ -220,6 +247,7 @@ struct DeviceHasher : TrHasher {
     }
 };
 static int32_t shape_of_state(stark_ctx* ctx, stark_fri_state* S, size_t n0, FriShape& sh) {
+    STARK_TRY(state_roots(S));
     std::string err;
     if (!sh.make(n0, S->schedule.data(), S->schedule.size(), S->roots.data(), err)) return ctx->fail(STARK_ERR_INVALID_ARG, err);
     return STARK_OK;
@@ -243,7 +271,7 @@ static int32_t prove_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, const fr
     stark_proof* P = new stark_proof(); auto t0 = now();
     DevBuf f0buf; const fr_t* f0 = f0_in;
     if (!f0) {
-        if (f0buf.alloc(n0 * sizeof(fr_t)) != hipSuccess) { delete P; return ctx->fail(STARK_ERR_OOM, "f0"); }
+        if (f0buf.alloc(ctx, n0 * sizeof(fr_t)) != hipSuccess) { delete P; return ctx->fail(STARK_ERR_OOM, "f0"); }
         int32_t rc = build_f0_dev_impl(ctx, a, s, e, t, n0, f0buf.fr(), nullptr); if (rc) { delete P; return rc; }
         f0 = f0buf.fr();
     }
@@ -264,12 +292,14 @@ int32_t stark_fri_sample_z(stark_ctx_t* ctx, stark_params_t* tp, uint64_t seed_z
 }
 int32_t stark_fri_fold_dev(stark_ctx_t* ctx, const uint64_t* f, size_t n, const uint64_t* z4, size_t m, uint64_t* out) {
     if (!ctx || !z4 || (!f && n) || (!out && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     return fold_dev(ctx, as_fr(f), n, load_fr(z4), m, as_fr(out));
 }
 int32_t stark_fri_fold(stark_ctx_t* ctx, const uint64_t* f, size_t n, const uint64_t* z4, size_t m, uint64_t* out) {
     if (!ctx || !z4 || (!f && n) || (!out && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (m < 2) return ctx->fail(STARK_ERR_INVALID_ARG, "m >= 2"); if (n % m) return ctx->fail(STARK_ERR_INVALID_ARG, "layer size must be divisible by m");
-    DevBuf df, dout; STARK_HIP(ctx, df.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(n / m * sizeof(fr_t)));
+    DevBuf df, dout; STARK_HIP(ctx, df.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(ctx, n / m * sizeof(fr_t)));
     if (n) STARK_HIP(ctx, hipMemcpyAsync(df.p, f, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(fold_dev(ctx, df.fr(), n, load_fr(z4), m, dout.fr()));
     if (n) STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, n / m * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -277,12 +307,14 @@ int32_t stark_fri_fold(stark_ctx_t* ctx, const uint64_t* f, size_t n, const uint
 }
 int32_t stark_fri_build_dev(stark_ctx_t* ctx, const uint64_t* f0, size_t n0, const size_t* schedule, size_t L, uint64_t seed_z, stark_fri_state_t** out) {
     if (!ctx || !f0 || !out || (!schedule && L)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     return fri_build_impl(ctx, as_fr(f0), n0, schedule, L, seed_z, out);
 }
 int32_t stark_fri_build(stark_ctx_t* ctx, const uint64_t* f0, size_t n0, const size_t* schedule, size_t L, uint64_t seed_z, stark_fri_state_t** out) {
     if (!ctx || !f0 || !out || (!schedule && L)) return STARK_ERR_INVALID_ARG;
-    DevBuf d; STARK_HIP(ctx, d.alloc(n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d.p, f0, n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
-    STARK_TRY(fri_build_impl(ctx, d.fr(), n0, schedule, L, seed_z, out)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+    STARK_TRY(ctx_enter(ctx));
+    DevBuf d; STARK_HIP(ctx, d.alloc(ctx, n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d.p, f0, n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(fri_build_impl(ctx, d.fr(), n0, schedule, L, seed_z, out)); return STARK_OK;
 }
 int32_t stark_fri_num_layers(stark_fri_state_t* s) { return s ? (int32_t)s->f.size() : STARK_ERR_INVALID_ARG; }
 size_t stark_fri_layer_len(stark_fri_state_t* s, int32_t l) { return (s && l >= 0 && (size_t)l < s->n.size()) ? s->n[l] : 0; }
@@ -290,36 +322,43 @@ int32_t stark_fri_layer_f(stark_fri_state_t* s, int32_t l, uint64_t* out) {
     if (!s || !out || l < 0 || (size_t)l >= s->f.size()) return STARK_ERR_INVALID_ARG; stark_ctx* ctx = s->ctx;
     STARK_HIP(ctx, hipMemcpyAsync(out, s->f[l], s->n[l] * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
-int32_t stark_fri_layer_root(stark_fri_state_t* s, int32_t l, uint64_t* out4) { if (!s || !out4 || l < 0 || (size_t)l >= s->roots.size()) return STARK_ERR_INVALID_ARG; store_fr(out4, s->roots[l]); return STARK_OK; }
+int32_t stark_fri_layer_root(stark_fri_state_t* s, int32_t l, uint64_t* out4) {
+    if (!s || !out4 || l < 0 || (size_t)l >= s->trees.size()) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(s->ctx)); STARK_TRY(state_roots(s)); store_fr(out4, s->roots[l]); return STARK_OK;
+}
 int32_t stark_fri_layer_z(stark_fri_state_t* s, int32_t l, uint64_t* out4) { if (!s || !out4 || l < 0 || (size_t)l >= s->z.size()) return STARK_ERR_INVALID_ARG; store_fr(out4, s->z[l]); return STARK_OK; }
 stark_tree_t* stark_fri_layer_tree(stark_fri_state_t* s, int32_t l) { return (s && l >= 0 && (size_t)l < s->trees.size()) ? s->trees[l] : nullptr; }
-int32_t stark_fri_state_free(stark_fri_state_t* s) { if (!s) return STARK_ERR_INVALID_ARG; (void)hipStreamSynchronize(s->ctx->stream); delete s; return STARK_OK; }
+int32_t stark_fri_state_free(stark_fri_state_t* s) { if (!s) return STARK_ERR_INVALID_ARG; delete s; return STARK_OK; }   // layers and levels return to the pool (stream-ordered reuse)
 
 int32_t stark_ali_merge_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt, const uint64_t* beta4,
                             const uint64_t* omega4, const uint64_t* z4, size_t n, uint64_t* f0, uint64_t* c_star4) {
     if (!ctx || !a || !s || !e || !t || !omega4 || !z4 || !f0 || (r_opt && !beta4)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     fr_t cs; STARK_TRY(ali_merge_dev_impl(ctx, as_fr(a), as_fr(s), as_fr(e), as_fr(t), as_fr(r_opt), beta4 ? load_fr(beta4) : host::h_zero(), load_fr(omega4), load_fr(z4), n, as_fr(f0), c_star4 ? &cs : nullptr));
     if (c_star4) store_fr(c_star4, cs); return STARK_OK;
 }
 int32_t stark_ali_merge(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt, const uint64_t* beta4,
                         const uint64_t* omega4, const uint64_t* z4, size_t n, uint64_t* f0, uint64_t* c_star4) {
     if (!ctx || !a || !s || !e || !t || !omega4 || !z4 || !f0 || (r_opt && !beta4)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     DevBuf d[6]; const uint64_t* src[5] = {a, s, e, t, r_opt};
-    for (int i = 0; i < 5; ++i) if (src[i]) { STARK_HIP(ctx, d[i].alloc(n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
-    STARK_HIP(ctx, d[5].alloc(n * sizeof(fr_t)));
+    for (int i = 0; i < 5; ++i) if (src[i]) { STARK_HIP(ctx, d[i].alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
+    STARK_HIP(ctx, d[5].alloc(ctx, n * sizeof(fr_t)));
     STARK_TRY(stark_ali_merge_dev(ctx, (const uint64_t*)d[0].p, (const uint64_t*)d[1].p, (const uint64_t*)d[2].p, (const uint64_t*)d[3].p, r_opt ? (const uint64_t*)d[4].p : nullptr, beta4, omega4, z4, n, (uint64_t*)d[5].p, c_star4));
     STARK_HIP(ctx, hipMemcpyAsync(f0, d[5].p, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
 int32_t stark_build_f0_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, size_t n0, uint64_t* f0, uint64_t* aux7) {
     if (!ctx || !a || !s || !e || !t || !f0) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     fr_t aux[7]; STARK_TRY(build_f0_dev_impl(ctx, as_fr(a), as_fr(s), as_fr(e), as_fr(t), n0, as_fr(f0), aux7 ? aux : nullptr));
     if (aux7) for (int i = 0; i < 7; ++i) store_fr(aux7 + 4 * i, aux[i]); return STARK_OK;
 }
 int32_t stark_build_f0(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, size_t n0, uint64_t* f0, uint64_t* aux7) {
     if (!ctx || !a || !s || !e || !t || !f0) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     DevBuf d[5]; const uint64_t* src[4] = {a, s, e, t};
-    for (int i = 0; i < 4; ++i) { STARK_HIP(ctx, d[i].alloc(n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
-    STARK_HIP(ctx, d[4].alloc(n0 * sizeof(fr_t)));
+    for (int i = 0; i < 4; ++i) { STARK_HIP(ctx, d[i].alloc(ctx, n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
+    STARK_HIP(ctx, d[4].alloc(ctx, n0 * sizeof(fr_t)));
     STARK_TRY(stark_build_f0_dev(ctx, (const uint64_t*)d[0].p, (const uint64_t*)d[1].p, (const uint64_t*)d[2].p, (const uint64_t*)d[3].p, n0, (uint64_t*)d[4].p, aux7));
     STARK_HIP(ctx, hipMemcpyAsync(f0, d[4].p, n0 * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
@@ -327,13 +366,15 @@ int32_t stark_build_f0(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, c
 int32_t stark_deep_fri_prove_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* f0, size_t n0,
                                  const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out) {
     if (!ctx || !out || (!schedule && L) || (!f0 && (!a || !s || !e || !t))) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     return prove_impl(ctx, as_fr(a), as_fr(s), as_fr(e), as_fr(t), as_fr(f0), n0, schedule, L, r, seed_z, out);
 }
 int32_t stark_deep_fri_prove(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* f0, size_t n0,
                              const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out) {
     if (!ctx || !out || (!schedule && L) || (!f0 && (!a || !s || !e || !t))) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     DevBuf d[5]; const uint64_t* src[5] = {a, s, e, t, f0};
-    for (int i = 0; i < 5; ++i) if ((i < 4 && !f0) || (i == 4 && f0)) { STARK_HIP(ctx, d[i].alloc(n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
+    for (int i = 0; i < 5; ++i) if ((i < 4 && !f0) || (i == 4 && f0)) { STARK_HIP(ctx, d[i].alloc(ctx, n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
     return stark_deep_fri_prove_dev(ctx, (const uint64_t*)d[0].p, (const uint64_t*)d[1].p, (const uint64_t*)d[2].p, (const uint64_t*)d[3].p, f0 ? (const uint64_t*)d[4].p : nullptr, n0, schedule, L, r, seed_z, out);
 }
 size_t stark_proof_len(stark_proof_t* p) { return p ? p->bytes.size() : 0; }
@@ -346,6 +387,7 @@ int32_t stark_proof_free(stark_proof_t* p) { if (!p) return STARK_ERR_INVALID_AR
 int32_t stark_ali_merge_shard_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* r_opt, const uint64_t* beta4,
                                   const uint64_t* omega4, const uint64_t* z4, size_t n_local, uint64_t j0, size_t n_global, uint64_t* f0, uint64_t* partial4) {
     if (!ctx || !a || !s || !e || !t || !z4 || !f0 || (r_opt && !beta4) || !n_global) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     const fr_t omega = omega4 ? load_fr(omega4) : fr_root_of_unity<PallasFr>((unsigned)ilog2(n_global));               // FriDomain::new_radix2(n).omega, fri.rs:53-56
     fr_t ps; STARK_TRY(ali_merge_dev_impl(ctx, as_fr(a), as_fr(s), as_fr(e), as_fr(t), as_fr(r_opt), beta4 ? load_fr(beta4) : host::h_zero(), omega, load_fr(z4), n_local, as_fr(f0),
                                           partial4 ? &ps : nullptr, j0, n_global, true));
@@ -353,11 +395,13 @@ int32_t stark_ali_merge_shard_dev(stark_ctx_t* ctx, const uint64_t* a, const uin
 }
 int32_t stark_ali_cstar_from_partials(stark_ctx_t* ctx, const uint64_t* partials, size_t k, size_t n_global, uint64_t* c_star4) {
     if (!ctx || (!partials && k) || !c_star4 || !n_global) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     fr_t acc = host::h_zero(); for (size_t i = 0; i < k; ++i) acc = host::h_add(acc, load_fr(partials + 4 * i));
     store_fr(c_star4, fr_mul<PallasFr>(acc, fr_inv<PallasFr>(host::h_u64(n_global)))); return STARK_OK;                  // c* = (1/n) * sum (lib.rs:44, :94)
 }
 int32_t stark_ali_challenges(stark_ctx_t* ctx, const uint64_t* digests16, size_t n0, uint64_t* aux12) {
     if (!ctx || !digests16 || !aux12 || n0 <= 1) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     fr_t h[5]; for (int c = 0; c < 4; ++c) h[c] = load_fr(digests16 + 4 * c); h[4] = host::h_u64(n0);
     fr_t seed_f; STARK_TRY(tr_hash_host1(ctx, "ALI/seed", std::vector<fr_t>(h, h + 5), &seed_f));                       // fri.rs:556-557
     fr_t z, beta; STARK_TRY(ali_sample_z_beta(ctx, "ALI/DEEP", n0, seed_f, &z, &beta));
@@ -365,6 +409,7 @@ int32_t stark_ali_challenges(stark_ctx_t* ctx, const uint64_t* digests16, size_t
 }
 int32_t stark_fri_plan_create(stark_ctx_t* ctx, const uint64_t* roots, size_t n0, const size_t* schedule, size_t L, size_t r, stark_fri_plan_t** out) {
     if (!ctx || !roots || !out || (!schedule && L)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     std::vector<fr_t> rt(L + 1); for (size_t l = 0; l <= L; ++l) rt[l] = load_fr(roots + 4 * l);
     stark_fri_plan* P = new stark_fri_plan(); P->ctx = ctx; P->plan.r = r;
     std::string err; if (!P->plan.shape.make(n0, schedule, L, rt.data(), err)) { delete P; return ctx->fail(STARK_ERR_INVALID_ARG, err); }

@@ -173,8 +173,9 @@ static int32_t lde_run(stark_ctx* ctx, const fr_t* evals, int log_n, int log_blo
 
 void stark::ntt_plans_free(stark_ctx* ctx) { for (auto& kv : ctx->plans) delete kv.second; ctx->plans.clear(); }
 
-static void set_ntt_attrs() {
-    static bool done = false; if (done) return; done = true;
+// Per-DEVICE kernel attributes (the default tile is 64 KiB + twiddles, above the 64 KiB a kernel may use without opting in):
+// called from stark_ctx_create with the context's device current, so a process holding contexts on several GPUs sets them on each.
+void stark::ntt_set_attrs() {
     (void)hipFuncSetAttribute((const void*)k_ntt_strided<PallasFr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_ntt_last<PallasFr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_ntt_strided<Bls12381Fr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
@@ -199,7 +200,7 @@ extern "C" {
 
 int32_t stark_ntt_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4) {
     if (!ctx || !data) return STARK_ERR_INVALID_ARG;
-    set_ntt_attrs();
+    STARK_TRY(ctx_enter(ctx));
     fr_t cs; if (coset4) cs = load_fr(coset4);
     if (field_id == STARK_FIELD_PALLAS_FR) return ntt_run<PallasFr>(ctx, as_fr(data), (int)log_n, 1, inverse != 0, coset4 ? &cs : nullptr, nullptr);
     if (field_id == STARK_FIELD_BLS12_381_FR) return ntt_run<Bls12381Fr>(ctx, as_fr(data), (int)log_n, 1, inverse != 0, coset4 ? &cs : nullptr, nullptr);
@@ -207,14 +208,15 @@ int32_t stark_ntt_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t
 }
 int32_t stark_ntt(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4) {
     if (!ctx || !data || log_n > 30) return STARK_ERR_INVALID_ARG;
-    size_t bytes = ((size_t)1 << log_n) * sizeof(fr_t); DevBuf d; STARK_HIP(ctx, d.alloc(bytes));
+    STARK_TRY(ctx_enter(ctx));
+    size_t bytes = ((size_t)1 << log_n) * sizeof(fr_t); DevBuf d; STARK_HIP(ctx, d.alloc(ctx, bytes));
     STARK_HIP(ctx, hipMemcpyAsync(d.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(stark_ntt_dev(ctx, field_id, (uint64_t*)d.p, log_n, inverse, coset4));
     STARK_HIP(ctx, hipMemcpyAsync(data, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
 }
 int32_t stark_lde_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* coset4, uint64_t* out) {
     if (!ctx || !evals || !out || log_n + log_blowup > 30) return STARK_ERR_INVALID_ARG;
-    set_ntt_attrs();
+    STARK_TRY(ctx_enter(ctx));
     fr_t cs; if (coset4) cs = load_fr(coset4);
     if (field_id == STARK_FIELD_PALLAS_FR) return lde_run<PallasFr>(ctx, as_fr(evals), (int)log_n, (int)log_blowup, coset4 ? &cs : nullptr, as_fr(out));
     if (field_id == STARK_FIELD_BLS12_381_FR) return lde_run<Bls12381Fr>(ctx, as_fr(evals), (int)log_n, (int)log_blowup, coset4 ? &cs : nullptr, as_fr(out));
@@ -222,7 +224,8 @@ int32_t stark_lde_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals,
 }
 int32_t stark_lde(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* coset4, uint64_t* out) {
     if (!ctx || !evals || !out || log_n + log_blowup > 30) return STARK_ERR_INVALID_ARG;
-    size_t n = (size_t)1 << log_n, N = n << log_blowup; DevBuf di, dout; STARK_HIP(ctx, di.alloc(n * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(N * sizeof(fr_t)));
+    STARK_TRY(ctx_enter(ctx));
+    size_t n = (size_t)1 << log_n, N = n << log_blowup; DevBuf di, dout; STARK_HIP(ctx, di.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, dout.alloc(ctx, N * sizeof(fr_t)));
     STARK_HIP(ctx, hipMemcpyAsync(di.p, evals, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_TRY(stark_lde_dev(ctx, field_id, (const uint64_t*)di.p, log_n, log_blowup, coset4, (uint64_t*)dout.p));
     STARK_HIP(ctx, hipMemcpyAsync(out, dout.p, N * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
@@ -230,7 +233,7 @@ int32_t stark_lde(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals, siz
 
 int32_t stark_ntt_columns_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, int32_t inverse) {
     if (!ctx || !slab) return STARK_ERR_INVALID_ARG;
-    set_ntt_attrs();
+    STARK_TRY(ctx_enter(ctx));
     if (field_id == STARK_FIELD_PALLAS_FR) return columns_run<PallasFr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, inverse != 0);
     if (field_id == STARK_FIELD_BLS12_381_FR) return columns_run<Bls12381Fr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, inverse != 0);
     return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
@@ -239,12 +242,12 @@ int32_t stark_ntt_columns_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab
 // (the caller passes N^-1 of the FULL transform for an inverse; the per-row n^-1 is not applied).
 int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t nrows, size_t log_cols, int32_t inverse, const uint64_t* scale4) {
     if (!ctx || !slab) return STARK_ERR_INVALID_ARG;
-    set_ntt_attrs();
+    STARK_TRY(ctx_enter(ctx));
     DevBuf sc; fr_t one_f;
-    if (scale4) { fr_t s = load_fr(scale4); STARK_HIP(ctx, sc.alloc(sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &s, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    if (scale4) { fr_t s = load_fr(scale4); STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &s, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
     else if (inverse) {   // suppress the plan's per-row n^-1: multiply by one
         one_f = field_id == STARK_FIELD_PALLAS_FR ? fr_one<PallasFr>() : fr_one<Bls12381Fr>();
-        STARK_HIP(ctx, sc.alloc(sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &one_f, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &one_f, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     int32_t rc;
     if (field_id == STARK_FIELD_PALLAS_FR) rc = ntt_run<PallasFr>(ctx, as_fr(slab), (int)log_cols, nrows, inverse != 0, nullptr, sc.p ? sc.fr() : nullptr);
@@ -257,6 +260,7 @@ int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, s
 
 int32_t stark_synth_column_dev(stark_ctx_t* ctx, uint64_t seed, uint64_t col, size_t i0, size_t n, uint64_t* out) {
     if (!ctx || (!out && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
     if (!n) return STARK_OK;
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, col, (uint64_t)i0, (uint64_t)n, as_fr(out));
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;

@@ -44,15 +44,32 @@ struct stark_ctx {
     void* scratch = nullptr; size_t scratch_bytes = 0;
     // NTT plans
     std::map<uint64_t, stark::NttPlan*> plans;
+    // Caching device allocator for the library's own temporaries, layers and tree levels: a block released here is reused by a
+    // later request of the same (rounded) size WITHOUT hipFree / hipMalloc, so the hot path neither synchronises the device nor
+    // pays allocation latency.  Safe because every use of such a block is ordered on this context's stream (the side stream
+    // joins the main one before anything it touched is released).  stark_ctx_trim() returns the cached blocks to the driver.
+    std::map<size_t, std::vector<void*>> pool_free;
+    std::map<void*, size_t> pool_live;
+    size_t pool_cached_bytes = 0;
+    // host-side caches of values that depend only on their key
+    struct ZKey { uint64_t seed; size_t level, size; bool operator<(const ZKey& o) const { return seed != o.seed ? seed < o.seed : (level != o.level ? level < o.level : size < o.size); } };
+    std::map<ZKey, stark::fr_t> z_cache;                                // fri_sample_z_ell(seed_z, level, size)  (fri.rs:59-82)
+    struct OmegaTab { int bits; stark::fr_t omega; stark::fr_t* lo; stark::fr_t* hi; int lo_bits; };
+    std::vector<OmegaTab> omega_tabs;                                  // two-level power tables of a domain generator (DomainH, deep_ali/src/lib.rs:109-125)
+    void* pinned = nullptr; size_t pinned_bytes = 0;                   // small pinned staging area for async uploads / downloads
 
     int32_t fail(int32_t code, const std::string& msg) { err = msg; return code; }
 };
 
+namespace stark {
+int32_t ctx_alloc(stark_ctx* ctx, size_t bytes, void** out);   // pooled device memory (see stark_ctx::pool_free)
+void ctx_release(stark_ctx* ctx, void* p);
+}
 struct stark_tree {
     stark_ctx* ctx = nullptr; stark_params* p = nullptr;
     size_t arity = 0; uint64_t label = 0;
     std::vector<stark::fr_t*> levels; std::vector<size_t> lens; std::vector<char> owned;
-    ~stark_tree() { for (size_t i = 0; i < levels.size(); ++i) if (owned[i] && levels[i]) (void)hipFree(levels[i]); }
+    ~stark_tree() { for (size_t i = 0; i < levels.size(); ++i) if (owned[i] && levels[i]) stark::ctx_release(ctx, levels[i]); }
 };
 
 
@@ -71,11 +88,12 @@ inline fr_t* as_fr(uint64_t* p) { return reinterpret_cast<fr_t*>(p); }
 inline fr_t load_fr(const uint64_t* p) { fr_t x; for (int i = 0; i < 4; ++i) { x.v[2 * i] = (uint32_t)p[i]; x.v[2 * i + 1] = (uint32_t)(p[i] >> 32); } return x; }
 inline void store_fr(uint64_t* p, const fr_t& x) { for (int i = 0; i < 4; ++i) p[i] = (uint64_t)x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32); }
 
-// RAII device buffer used inside entry points (freed on every return path).
+// RAII device buffer used inside entry points (returned to the context's pool on every return path).
 struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 32); }
+    stark_ctx* ctx = nullptr; void* p = nullptr;
+    DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) ctx_release(ctx, p); }
+    hipError_t alloc(stark_ctx* c, size_t bytes) { ctx = c; return ctx_alloc(c, bytes, &p) == STARK_OK ? hipSuccess : hipErrorOutOfMemory; }
     fr_t* fr() const { return reinterpret_cast<fr_t*>(p); }
     void* release() { void* q = p; p = nullptr; return q; }
 };
@@ -88,7 +106,12 @@ int32_t ctx_transcript_params(stark_ctx* ctx, stark_params** out);
 int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out);
 int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out);
 int32_t ctx_side_stream(stark_ctx* ctx, hipStream_t* out);
+int32_t ctx_enter(stark_ctx* ctx);                                   // makes the context's device current (every entry point)
+void ntt_set_attrs();                                                // per-device kernel attributes of the NTT kernels (capi_ntt.hip)
 void ntt_plans_free(stark_ctx* ctx);
+int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const fr_t* f_next, size_t n, size_t m, fr_t* h);
+int32_t merkle_build_on(stark_ctx* ctx, hipStream_t st, stark_params* p, size_t arity, uint64_t label, const fr_t* leaves, size_t n, int pairs, const fr_t* cp, size_t cp_div,
+                        uint64_t first_pos, uint32_t level0, size_t stop_at_len, bool adopt, stark_tree** out);
 int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev);
 int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev);
 int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out);   // one hash, host in/out

@@ -33,6 +33,15 @@ __global__ void __launch_bounds__(256) k_fri_fold_pow2(const fr_t* __restrict__ 
     for (int s = 0; s < log_g; ++s) acc = fr_add<F>(acc, shfl_xor_fr(acc, 1 << s));
     if (live && (tid & ((1u << log_g) - 1)) == 0) stg(out + (first >> log_m), acc);
 }
+// zp[t] = z^t, t < m (square-and-multiply per lane; m is a fold arity, at most a few hundred).
+template <class F>
+__global__ void __launch_bounds__(64) k_zpows(fr_t z, uint64_t m, fr_t* __restrict__ zp) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    fr_t acc = fr_one<F>(), b = z;
+    for (uint64_t e = t; e; e >>= 1) { if (e & 1) acc = fr_mul<F>(acc, b); b = fr_sqr<F>(b); }
+    stg(zp + t, acc);
+}
 // General m (>= 2, any): one lane per output.
 template <class F>
 __global__ void __launch_bounds__(256) k_fri_fold_any(const fr_t* __restrict__ f, uint64_t n_out, const fr_t* __restrict__ zp, uint64_t m, fr_t* __restrict__ out) {

@@ -99,7 +99,7 @@ int hc_leaf_pair(void* tparams, const uint64_t* f, const uint64_t* f_next, size_
 }
 int hc_hash_ds_level(void* params, int mode, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in0, const uint64_t* in1, size_t n_in, uint64_t* out) {
     HcParams* P = (HcParams*)params;
-    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode;
+    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode; J.cp_div = 1;
     J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
     std::vector<fr_t> a(n_in), b(in1 ? n_in : 0), st(P->dev.t);
     for (size_t i = 0; i < n_in; ++i) { a[i] = ld4(in0 + 4 * i); if (in1) b[i] = ld4(in1 + 4 * i); }

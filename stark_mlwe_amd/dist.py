@@ -75,12 +75,16 @@ class HipProvider:
     def __init__(self, ctx, field=0, device="cuda"):
         self.ctx, self.lib, self.field, self.device = ctx, ctx.lib, field, device
 
-    # Stream discipline.  The orchestration mixes torch device ops (slices, zeros, index gathers, staging copies, RCCL) with
-    # library kernels.  If the context was created ON torch's current stream (a real, non-default stream: bench.py does
-    # this), one stream orders everything.  Otherwise the library runs on its own non-blocking stream, which does not
-    # even synchronise with the default stream, so every library call is bracketed by explicit synchronisation.
+    # Stream discipline (include/stark_mlwe.h "Stream rule").  The orchestration mixes torch device ops (slices, zeros, index
+    # gathers, staging copies, RCCL) with library kernels.  If the context runs ON torch's current stream (bench.py hands it a
+    # dedicated torch stream; Context(stream=None) is the legacy default stream, which is also torch's default), one stream
+    # orders everything.  Otherwise (a STREAM_PRIVATE context, or torch moved to another stream) every library call is
+    # bracketed by explicit synchronisation.
     def _shared(self):
-        return self.ctx.stream_handle != 0 and self.ctx.stream_handle == torch.cuda.current_stream(self.device).cuda_stream
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if self.ctx.private_stream:
+            return False
+        return self.ctx.stream_handle == cur
 
     def _run(self, fn, *args):
         shared = self._shared()

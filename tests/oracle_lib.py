@@ -182,6 +182,12 @@ class Oracle:
         d = A(data); log_n = int(d.shape[0]).bit_length() - 1; out = np.zeros_like(d)
         self.l.oracle_dft_naive(field, P(d), C.c_uint(log_n), 1 if inverse else 0, P(out)); return out
 
+    def poly_eval_many(self, field, coeffs, points):
+        """Horner: sum_j coeffs[j] * x^j at every x in points (the definition; O(n) per point, all host cores)."""
+        c, p = A(coeffs), A(points).reshape(-1, 4); out = np.zeros_like(p)
+        assert self.l.oracle_poly_eval_many(field, P(c), C.c_size_t(c.shape[0]), P(p), C.c_size_t(p.shape[0]), P(out)) == 0
+        return out
+
     def lde(self, field, evals, log_blowup, coset=None):
         d = A(evals); log_n = int(d.shape[0]).bit_length() - 1; out = np.zeros((d.shape[0] << log_blowup, 4), np.uint64)
         self.l.oracle_lde(field, P(d), C.c_uint(log_n), C.c_uint(log_blowup), P(None if coset is None else A(coset)), P(out)); return out

@@ -96,8 +96,9 @@ def _prove_worker(rank, world, port, log_n0, schedule, r, q):
             import ctypes as C
             ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
             ctx = Context(0, C.c_void_p(ts.cuda_stream))
-        else:                 # ... or the library on its own stream: the provider then brackets every call with explicit syncs
-            ctx = Context(0)
+        else:                 # ... or the library on a private stream: the provider then brackets every call with explicit syncs
+            from stark_mlwe_amd.api import STREAM_PRIVATE
+            ctx = Context(0, STREAM_PRIVATE)
         o = oracle_lib.Oracle(); prov = sd.HipProvider(ctx)
         assert prov._shared() == (log_n0 >= 16)
         n0 = 1 << log_n0; nl = n0 // world
