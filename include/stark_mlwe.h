@@ -180,6 +180,20 @@ size_t  stark_proof_size_estimate(stark_proof_t* p);                /* deep_fri_
 double  stark_proof_stage_ms(stark_proof_t* p, int32_t stage);     /* 0 build_f0, 1 fri_build, 2 queries+encode */
 int32_t stark_proof_free(stark_proof_t* p);
 
+/* ---- verification (next row N3) --------------------------------------------------------------------
+ * deep_fri_verify (fri.rs:643-762) over the canonical proof bytes stark_proof_bytes returns; *accepted = 1 / 0 (the reference
+ * returns bool; bytes that do not decode are rejected, inputs on which the reference would panic are rejected).  seed_z is
+ * DeepFriParams.seed_z, carried for signature parity (the reference's verifier does not read it).  Host index logic in the
+ * library, every hash (leaf pairs, DS nodes) batched onto the GPU kernels of the prover. */
+int32_t stark_deep_fri_verify(stark_ctx_t* ctx, const uint8_t* proof, size_t len, const size_t* schedule, size_t L, size_t r, uint64_t seed_z, int32_t* accepted);
+/* MerkleProver::new(MerkleChannelCfg::new(cfg_arity).with_tree_label(tree_label)).verify_single / .verify_pairs
+ * (merkle/src/lib.rs:800-812, 841-855 over verify_many_ds :587-722 and verify_pairs_ds :723-773); `proof` = the canonical
+ * MerkleProof encoding stark_merkle_open returns. */
+int32_t stark_merkle_verify_many_ds(stark_ctx_t* ctx, size_t cfg_arity, uint64_t tree_label, const uint64_t* root4, const size_t* indices, size_t k, const uint64_t* values,
+                                    const uint8_t* proof, size_t len, int32_t* accepted);
+int32_t stark_merkle_verify_pairs_ds(stark_ctx_t* ctx, size_t cfg_arity, uint64_t tree_label, const uint64_t* root4, const size_t* indices, size_t k, const uint64_t* f_vals, const uint64_t* cp_vals,
+                                     const uint8_t* proof, size_t len, int32_t* accepted);
+
 /* ---- One trace sharded over several GPUs ------------------------------------------
  * The commit phase shards by contiguous blocks (folds, leaf hashes and lower Merkle levels are
  * block-local: stark_fri_fold_dev, stark_leaf_pair_hash_dev, stark_merkle_build_dev with first_pos /

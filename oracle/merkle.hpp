@@ -117,6 +117,7 @@ static inline bool verify_many_ds(const Fr& root, const std::vector<size_t>& ind
     if (proof.siblings.size() != proof.group_sizes.size()) return false;
     size_t arity = proof.arity;
     if (!ok_width(arity, dp.t)) return false;
+    if (arity == 0) throw std::string("verify_many_ds: arity 0 passes the width guard for t = 9 and the reference then divides by it (panic)");
     std::map<size_t, Fr> m; for (size_t k = 0; k < indices.size(); ++k) m[indices[k]] = values[k];
     std::vector<size_t> cur_i = req; std::vector<Fr> cur_v; for (size_t i : cur_i) cur_v.push_back(m[i]);
     for (size_t level = 0; level < proof.siblings.size(); ++level) {

@@ -36,7 +36,7 @@ static bool decode_proof(const uint8_t* b, size_t n, DeepFriProof& p) {
     Dec d{b, n};
     size_t nr = d.len(); for (size_t i = 0; i < nr && !d.bad; ++i) p.roots.push_back(d.fr());
     size_t nl = d.len();
-    for (size_t i = 0; i < nl && !d.bad; ++i) { LayerBatchProof lb; lb.hashed_leaves = d.u8() != 0; lb.child_indices = d.idxs(); lb.child_proof = d.mproof(); lb.parent_indices = d.idxs(); lb.parent_proof = d.mproof(); p.layer_batches.layers.push_back(lb); }
+    for (size_t i = 0; i < nl && !d.bad; ++i) { LayerBatchProof lb; { uint8_t h = d.u8(); if (h > 1) d.bad = true; lb.hashed_leaves = h == 1; }   /* bool = one byte, 0 or 1 */ lb.child_indices = d.idxs(); lb.child_proof = d.mproof(); lb.parent_indices = d.idxs(); lb.parent_proof = d.mproof(); p.layer_batches.layers.push_back(lb); }
     p.layer_batches.final_proof = d.mproof();
     size_t nq = d.len();
     for (size_t i = 0; i < nq && !d.bad; ++i) {
@@ -150,6 +150,13 @@ int oracle_merkle_open_verify(void* h, const size_t* idx, size_t k, const uint64
     if (cp_values) { std::vector<std::pair<Fr, Fr>> ps; for (size_t i = 0; i < k; ++i) ps.push_back({ld(values + 4 * i), ld(cp_values + 4 * i)});
                      return verify_pairs_ds(o->t.root, ix, ps, pr, o->t.cfg.tree_label, o->t.cfg.params) ? 1 : 0; }
     return verify_many_ds(o->t.root, ix, ldv(values, k), pr, o->t.cfg.tree_label, o->t.cfg.params) ? 1 : 0;
+}
+// open_union_of_paths -> canonical MerkleProof encoding; returns the length (buf may be NULL)
+size_t oracle_merkle_open_bytes(void* h, const size_t* idx, size_t k, uint8_t* buf, size_t cap) {
+    OTree* o = (OTree*)h; std::vector<size_t> ix(idx, idx + k);
+    MerkleProof pr = o->t.open(ix); Enc e; e.mproof(pr); std::vector<uint8_t>& b = e.b;
+    if (buf && cap >= b.size()) memcpy(buf, b.data(), b.size());
+    return b.size();
 }
 void oracle_merkle_free(void* h) { delete (OTree*)h; }
 

@@ -87,6 +87,9 @@ SIGNATURES = {
     "stark_proof_size_estimate": (sz, [vp]),
     "stark_proof_stage_ms": (C.c_double, [vp, i32]),
     "stark_proof_free": (i32, [vp]),
+    "stark_deep_fri_verify": (i32, [vp, vp, sz, vp, sz, sz, u64, C.POINTER(i32)]),
+    "stark_merkle_verify_many_ds": (i32, [vp, sz, u64, vp, vp, sz, vp, vp, sz, C.POINTER(i32)]),
+    "stark_merkle_verify_pairs_ds": (i32, [vp, sz, u64, vp, vp, sz, vp, vp, vp, sz, C.POINTER(i32)]),
     "stark_ali_merge_shard_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, u64, sz, vp, vp]),
     "stark_ali_cstar_from_partials": (i32, [vp, vp, sz, sz, vp]),
     "stark_ali_challenges": (i32, [vp, vp, sz, vp]),

@@ -380,6 +380,28 @@ class Context:
             self.lib.stark_proof_free(h)
         return bytes(buf), est, ms
 
+    def deep_fri_verify(self, params: DeepFriParams, proof: bytes) -> bool:
+        """deep_fri_verify (fri.rs:643-762) on canonical proof bytes."""
+        sch = np.ascontiguousarray(params.schedule, dtype=np.uint64)
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0")
+        ok = C.c_int32(0)
+        self._chk(self.lib.stark_deep_fri_verify(self.h, buf, len(proof), _ptr(sch), len(sch), params.r, params.seed_z, C.byref(ok)))
+        return bool(ok.value)
+
+    def merkle_verify_single(self, cfg, root, indices, leaves, proof: bytes) -> bool:
+        """MerkleProver::verify_single (merkle/src/lib.rs:800-812)."""
+        ix = np.ascontiguousarray(indices, dtype=np.uint64); lv = _arr(leaves)
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0"); ok = C.c_int32(0)
+        self._chk(self.lib.stark_merkle_verify_many_ds(self.h, cfg.arity, cfg.tree_label, _ptr(_arr(root)), _ptr(ix), len(ix), _ptr(lv), buf, len(proof), C.byref(ok)))
+        return bool(ok.value)
+
+    def merkle_verify_pairs(self, cfg, root, indices, f_vals, cp_vals, proof: bytes) -> bool:
+        """MerkleProver::verify_pairs (merkle/src/lib.rs:841-855)."""
+        ix = np.ascontiguousarray(indices, dtype=np.uint64); f, cp = _arr(f_vals), _arr(cp_vals)
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0"); ok = C.c_int32(0)
+        self._chk(self.lib.stark_merkle_verify_pairs_ds(self.h, cfg.arity, cfg.tree_label, _ptr(_arr(root)), _ptr(ix), len(ix), _ptr(f), _ptr(cp), buf, len(proof), C.byref(ok)))
+        return bool(ok.value)
+
     def _proof_out(self, h):
         try:
             ln = self.lib.stark_proof_len(h)

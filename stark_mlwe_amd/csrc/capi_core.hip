@@ -60,6 +60,8 @@ void ctx_release(stark_ctx* ctx, void* p) {
     const size_t sz = it->second; ctx->pool_live.erase(it);
     ctx->pool_free[sz].push_back(p); ctx->pool_cached_bytes += sz;
 }
+int32_t hash_ds_scattered(stark_ctx* ctx, stark_params* p, int mode, size_t arity, size_t chunk, uint32_t level, uint64_t label, const uint64_t* positions_dev,
+                          const fr_t* in0, const fr_t* in1, size_t n_hashes, fr_t* out);
 int32_t ctx_enter(stark_ctx* ctx) {
     if (!ctx) return STARK_ERR_INVALID_ARG;
     int cur = -1;
@@ -351,9 +353,10 @@ int32_t stark_poseidon_hash_with_ds(stark_ctx_t* ctx, stark_params_t* p, const u
     return hash_stream(ctx, p, 1, nullptr, 0, in, cnt, load_fr(ds_tag), 1, out);
 }
 static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* p, int mode, size_t arity, uint32_t level, uint64_t pos0, uint64_t label,
-                              const fr_t* in0, const fr_t* in1, size_t n_in, fr_t* out, size_t cp_div = 1) {
-    DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode; J.cp_div = cp_div ? cp_div : 1;
-    J.n_out = mode == 1 ? n_in : (n_in + arity - 1) / arity;
+                              const fr_t* in0, const fr_t* in1, size_t n_in, fr_t* out, size_t cp_div = 1, const uint64_t* pos_list = nullptr, size_t chunk = 0) {
+    DsJob J; J.pos_list = pos_list; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = pos0; J.arity = arity; J.n_in = n_in; J.mode = mode; J.cp_div = cp_div ? cp_div : 1;
+    if (chunk) J.arity = chunk;          // the verifier's groups: DS field `arity` as given, `chunk` children per hash (a short last chunk of the proof's level)
+    J.n_out = mode == 1 ? n_in : (n_in + J.arity - 1) / J.arity;
     if (!J.n_out) return STARK_OK;
     if (use_pair(p->dev.t) && J.n_out <= 8192) {
         // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
@@ -370,6 +373,13 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* 
     hipLaunchKernelGGL(k_hash_ds, dim3((unsigned)((J.n_out + block - 1) / block)), dim3(block), poseidon_lds(p->dev.t, block), st, p->dev, J, in0, in1, out);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
+}  // extern "C"
+// DS hashes with scattered positions (the verifier's union-of-paths levels): hash k = H([arity, level, positions[k], label] || chunk children)
+int32_t stark::hash_ds_scattered(stark_ctx* ctx, stark_params* p, int mode, size_t arity, size_t chunk, uint32_t level, uint64_t label, const uint64_t* positions_dev,
+                                 const fr_t* in0, const fr_t* in1, size_t n_hashes, fr_t* out) {
+    return launch_hash_ds(ctx, ctx->stream, p, mode, arity, level, 0, label, in0, in1, mode == 1 ? n_hashes : n_hashes * chunk, out, 1, positions_dev, mode == 1 ? 0 : chunk);
+}
+extern "C" {
 int32_t stark_poseidon_hash_ds_batch_dev(stark_ctx_t* ctx, stark_params_t* p, size_t arity, uint32_t level, uint64_t pos0, uint64_t label, const uint64_t* in, size_t n_in, uint64_t* out) {
     if (!ctx || !p || !in || !out || arity == 0) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));

@@ -11,6 +11,7 @@
 #include "host_util.hpp"
 #include "poseidon_dev.hpp"
 #include "fri_plan.hpp"
+#include "fri_verify.hpp"
 
 using namespace stark;
 
@@ -163,5 +164,49 @@ size_t hc_fri_plan_assemble(void* p, const uint64_t* values, size_t n_values, ui
     return b.size();
 }
 void hc_fri_plan_free(void* p) { delete (HcPlan*)p; }
+
+// ---- verifier (fri_verify.hpp) with every hash computed by the host instantiation of the kernel bodies -------------
+struct HcVerifyHasher : VerifyHasher {
+    void* tp; explicit HcVerifyHasher(void* t) : tp(t) {}
+    std::map<int, HcParams*> mp;
+    ~HcVerifyHasher() { for (auto& kv : mp) delete kv.second; }
+    HcParams* params(size_t arity) { int t = host::width_for_arity(arity); auto it = mp.find(t); if (it != mp.end()) return it->second; HcParams* P = new HcParams(); P->ref = host::consts_for_width(t); bind(P); mp[t] = P; return P; }
+    int32_t leaf_pairs(const fr_t* f, const fr_t* s, size_t n, fr_t* out) override {
+        std::vector<uint64_t> a(4 * n), b(4 * n), o(4 * n);
+        for (size_t i = 0; i < n; ++i) { st4(a.data() + 4 * i, f[i]); st4(b.data() + 4 * i, s[i]); }
+        hc_leaf_pair(tp, a.data(), b.data(), n, 1, o.data());
+        for (size_t i = 0; i < n; ++i) out[i] = ld4(o.data() + 4 * i);
+        return 0;
+    }
+    int32_t ds_nodes(size_t arity, size_t chunk, uint32_t level, uint64_t label, const uint64_t* positions, const fr_t* children, size_t n, fr_t* out) override {
+        HcParams* P = params(arity); std::vector<fr_t> st(P->dev.t);
+        DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(level); J.label_f = host::h_u64(label); J.pos0 = 0; J.arity = chunk; J.n_in = n * chunk; J.n_out = n; J.mode = 0; J.pos_list = positions;
+        for (size_t k = 0; k < n; ++k) { ArrayState s{st.data()}; out[k] = hash_ds_body(s, P->dev, J, children, nullptr, k); }
+        return 0;
+    }
+    int32_t ds_pair_leaves(size_t arity, uint64_t label, const uint64_t* positions, const fr_t* f, const fr_t* cp, size_t n, fr_t* out) override {
+        HcParams* P = params(arity); std::vector<fr_t> st(P->dev.t);
+        DsJob J; J.arity_f = host::h_u64(arity); J.level_f = host::h_u64(0xFFFFFFFFu); J.label_f = host::h_u64(label); J.pos0 = 0; J.arity = arity; J.n_in = n; J.n_out = n; J.mode = 1; J.pos_list = positions;
+        for (size_t k = 0; k < n; ++k) { ArrayState s{st.data()}; out[k] = hash_ds_body(s, P->dev, J, f, cp, k); }
+        return 0;
+    }
+};
+// 1 accept, 0 reject, negative: internal error
+int hc_deep_fri_verify(void* tparams, const uint8_t* bytes, size_t len, const size_t* schedule, size_t L, size_t r) {
+    DeepFriProofHost P; if (!decode_proof(bytes, len, P)) return 0;
+    HcVerifyHasher H(tparams); bool ok = false;
+    int32_t rc = deep_fri_verify_host(H, P, schedule, L, r, ok); if (rc) return rc;
+    return ok ? 1 : 0;
+}
+// MerkleProver::verify_single / verify_pairs (merkle/src/lib.rs:800-855) over the canonical MerkleProof encoding
+int hc_merkle_verify(void* tparams, int pairs, size_t cfg_arity, uint64_t label, const uint64_t* root, const size_t* idx, size_t k, const uint64_t* vals, const uint64_t* cp, const uint8_t* proof, size_t len) {
+    ByteReader R(proof, len); MerkleProofHost pr; if (!dec_mproof(R, pr) || R.left()) return 0;
+    HcVerifyHasher H(tparams); bool ok = false;
+    std::vector<size_t> ix(idx, idx + k); std::vector<fr_t> v(k), c(k);
+    for (size_t i = 0; i < k; ++i) { v[i] = ld4(vals + 4 * i); if (pairs) c[i] = ld4(cp + 4 * i); }
+    int32_t rc = pairs ? verify_pairs_ds_host(H, cfg_arity, ld4(root), ix, v, c, pr, label, ok) : verify_many_ds_host(H, cfg_arity, ld4(root), ix, v, pr, label, ok);
+    if (rc) return rc;
+    return ok ? 1 : 0;
+}
 
 }  // extern "C"

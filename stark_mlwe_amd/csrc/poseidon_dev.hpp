@@ -131,7 +131,10 @@ template <class S> FR_HD fr_t leaf_pair_body(const S& s, const PoseidonDev& P, c
 //   mode 0 (node level): children_k = in0[k*arity .. min((k+1)*arity, n_in))
 //   mode 1 (pair leaf) : children_k = {in0[k], in1[k / cp_div]}  (merkle/src/lib.rs:380-388); in1 == nullptr: the second
 //                        child is zero (fri.rs:266).  cp_div = m serves commit_pairs(f_l, s_l) with s_l the view f_{l+1}[i/m].
-struct DsJob { fr_t arity_f, level_f, label_f; uint64_t pos0; size_t arity, n_in, n_out; int mode; size_t cp_div = 1; };
+//   pos_list != nullptr: hash k carries DS position pos_list[k] instead of pos0 + k (the verifier's union-of-paths levels, whose
+//                        parents are scattered; merkle/src/lib.rs:683-689).
+struct DsJob { fr_t arity_f, level_f, label_f; uint64_t pos0; size_t arity, n_in, n_out; int mode; size_t cp_div = 1; const uint64_t* pos_list = nullptr; };
+FR_HD uint64_t ds_position(const DsJob& J, size_t k) { return J.pos_list ? J.pos_list[k] : J.pos0 + k; }
 FR_HD fr_t ds_pair_child(const DsJob& J, const fr_t* in0, const fr_t* in1, size_t k, size_t c) {
     if (c == 0) return ldg(in0 + k);
     return in1 ? ldg(in1 + k / J.cp_div) : fr_zero<PF>();
@@ -145,7 +148,7 @@ template <class S> FR_HD fr_t hash_ds_body(const S& s, const PoseidonDev& P, con
     int cur = 0; fr_t res = fr_zero<PF>();
     for (size_t q = 0; q < total; ++q) {
         fr_t x;
-        if (q == 0) x = J.arity_f; else if (q == 1) x = J.level_f; else if (q == 2) x = fr_from_u64<PF>(J.pos0 + k); else if (q == 3) x = J.label_f;
+        if (q == 0) x = J.arity_f; else if (q == 1) x = J.level_f; else if (q == 2) x = fr_from_u64<PF>(ds_position(J, k)); else if (q == 3) x = J.label_f;
         else if (q == total - 1) x = fr_one<PF>();
         else { size_t c = q - 4; x = J.mode == 1 ? ds_pair_child(J, in0, in1, k, c) : ldg(in0 + k * J.arity + c); }
         s.st(cur, fr_add<PF>(s.ld(cur), x));

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k
             for (int cur = 0; cur < rate && q < total; ++cur, ++q) {
                 if (cur < o0 || cur >= o1) continue;
                 fr_t x;
-                if (q == 0) x = J.arity_f; else if (q == 1) x = J.level_f; else if (q == 2) x = fr_from_u64<PF>(J.pos0 + k); else if (q == 3) x = J.label_f;
+                if (q == 0) x = J.arity_f; else if (q == 1) x = J.level_f; else if (q == 2) x = fr_from_u64<PF>(ds_position(J, k)); else if (q == 3) x = J.label_f;
                 else if (q == total - 1) x = fr_one<PF>();
                 else { size_t c = q - 4; x = J.mode == 1 ? ds_pair_child(J, in0, in1, k, c) : ldg(in0 + k * J.arity + c); }
                 s.sto(cur, fr_add<PF>(s.ld(cur), x));

@@ -86,6 +86,20 @@ class HostCheck:
         return HcPlan(self, vp(h))
 
 
+def _hc_verify(self, tparams, proof: bytes, schedule, r):
+    sch = np.ascontiguousarray(schedule, dtype=np.uint64); buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0")
+    return self.l.hc_deep_fri_verify(tparams, buf, C.c_size_t(len(proof)), P(sch), C.c_size_t(len(sch)), C.c_size_t(r))
+
+
+def _hc_merkle_verify(self, tparams, pairs, cfg_arity, label, root, idx, vals, cp, proof: bytes):
+    ix = np.ascontiguousarray(idx, dtype=np.uint64); buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0")
+    return self.l.hc_merkle_verify(tparams, 1 if pairs else 0, C.c_size_t(cfg_arity), C.c_uint64(label), P(A(root)), P(ix), C.c_size_t(len(ix)), P(A(vals)), P(None if cp is None else A(cp)), buf, C.c_size_t(len(proof)))
+
+
+HostCheck.deep_fri_verify = _hc_verify
+HostCheck.merkle_verify = _hc_merkle_verify
+
+
 class HcPlan:
     def __init__(self, hc, h): self.hc, self.h = hc, h
 

@@ -204,6 +204,10 @@ class OTree:
         ix = np.ascontiguousarray(idx, dtype=np.uint64); ns = C.c_size_t()
         rc = self.o.l.oracle_merkle_open_verify(self.h, P(ix), C.c_size_t(len(ix)), P(A(values)), P(None if cp_values is None else A(cp_values)), C.byref(ns))
         return rc, ns.value
+    def open_bytes(self, idx):
+        ix = np.ascontiguousarray(idx, dtype=np.uint64); self.o.l.oracle_merkle_open_bytes.restype = C.c_size_t
+        n = self.o.l.oracle_merkle_open_bytes(self.h, P(ix), C.c_size_t(len(ix)), None, C.c_size_t(0)); buf = (C.c_uint8 * n)()
+        self.o.l.oracle_merkle_open_bytes(self.h, P(ix), C.c_size_t(len(ix)), buf, C.c_size_t(n)); return bytes(buf)
     def free(self): self.o.l.oracle_merkle_free(self.h)
 
 
