@@ -74,6 +74,9 @@ int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr);
 int32_t stark_free(stark_ctx_t* ctx, void* dptr);
 int32_t stark_memcpy_h2d(stark_ctx_t* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int32_t stark_memcpy_d2h(stark_ctx_t* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Diagnostic: lane-level v_mad_u64_u32 (32x32+64 multiply-accumulate) issue rate of this device, measured live with every
+ * SIMD saturated — the roofline `peak` of the integer-VALU-bound Poseidon kernels (bench.py "poseidon.roofline"). */
+int32_t stark_diag_mac_rate(stark_ctx_t* ctx, double* lane_macs_per_s);
 /* HIP-event timing on the context's stream (bench.py measures kernels with these). */
 int32_t stark_timer_start(stark_ctx_t* ctx);
 int32_t stark_timer_stop_ms(stark_ctx_t* ctx, float* ms);
@@ -235,6 +238,33 @@ int32_t stark_lde_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* evals,
  *   phase B: `nrows` contiguous NTTs of size 2^log_cols (plain stark_ntt batched over rows). */
 int32_t stark_ntt_columns_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, int32_t inverse);
 int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t nrows, size_t log_cols, int32_t inverse, const uint64_t* scale4);
+/*   phase A of a COSET transform: as stark_ntt_columns_dev (forward), with x[j] *= shift4^j on load, j = the element's natural
+ *            index in the whole vector (row * 2^(log_n-log_rows) + col0 + local column) — one of the 2^log_blowup cosets of an LDE.
+ *   stark_permute3_dev: dst (contiguous) = the [d0][d1][d2] array src with its axes permuted to (p0, p1, p2) — the layout
+ *            changes on either side of an all-to-all (32-byte elements).
+ *   stark_interleave_dev: dst[k*stride + offset] = src[k], k < n — the coset transforms of an LDE into natural order. */
+int32_t stark_ntt_columns_coset_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, const uint64_t* shift4);
+int32_t stark_permute3_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t d0, size_t d1, size_t d2, int32_t p0, int32_t p1, int32_t p2);
+int32_t stark_interleave_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t n, size_t stride, size_t offset);
+
+/* ---- the communicator (RCCL over xGMI; one process per GPU) ------------------------------------------------------------
+ * The exchanges of the path behind the boundary, so that a host without torch can drive several GPUs:
+ * rank 0 calls stark_comm_unique_id and passes the 128 bytes to its peers by its own means; every rank then calls
+ * stark_comm_init on its context (collective: returns when all ranks have joined).  The data-path calls below are enqueued on
+ * the context's stream (no host synchronisation) and must be made by all ranks in the same order.  Without a usable RCCL the
+ * calls fail with STARK_ERR_RCCL; nothing else in the library depends on it. */
+#define STARK_COMM_ID_BYTES 128
+int32_t stark_comm_unique_id(uint8_t* id128);
+int32_t stark_comm_init(stark_ctx_t* ctx, int32_t nranks, int32_t rank, const uint8_t* id128);
+int32_t stark_comm_destroy(stark_ctx_t* ctx);
+int32_t stark_comm_size(stark_ctx_t* ctx);
+int32_t stark_comm_rank(stark_ctx_t* ctx);
+/* all-to-all: chunk q (bytes_per_peer) of `send` goes to rank q; chunk p of `recv` is what rank p sent here — the row/column
+ * transpose of the six-step NTT, one message per peer link.  send != recv. */
+int32_t stark_comm_all_to_all_dev(stark_ctx_t* ctx, const void* send, void* recv, size_t bytes_per_peer);
+int32_t stark_comm_all_gather_dev(stark_ctx_t* ctx, const void* send, void* recv, size_t bytes);
+int32_t stark_comm_all_reduce_u64_dev(stark_ctx_t* ctx, const void* send, void* recv, size_t count);   /* SUM of uint64 words (send == recv allowed) */
+int32_t stark_comm_gather_dev(stark_ctx_t* ctx, const void* send, void* recv, size_t bytes, int32_t root);
 
 /* ---- synthetic inputs for benchmarks (DESIGN.md "Synthetic inputs") ------------------------------- */
 int32_t stark_synth_column_dev(stark_ctx_t* ctx, uint64_t seed, uint64_t col, size_t i0, size_t n, uint64_t* out);

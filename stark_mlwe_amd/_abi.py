@@ -37,6 +37,7 @@ SIGNATURES = {
     "stark_free": (i32, [vp, vp]),
     "stark_memcpy_h2d": (i32, [vp, vp, vp, sz]),
     "stark_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+    "stark_diag_mac_rate": (i32, [vp, C.POINTER(C.c_double)]),
     "stark_timer_start": (i32, [vp]),
     "stark_timer_stop_ms": (i32, [vp, C.POINTER(C.c_float)]),
     "stark_poseidon_params_upload": (i32, [vp, i32, i32, i32, vp, vp, vp, vpp]),
@@ -104,6 +105,18 @@ SIGNATURES = {
     "stark_lde_dev": (i32, [vp, i32, vp, sz, sz, vp, vp]),
     "stark_ntt_columns_dev": (i32, [vp, i32, vp, sz, sz, sz, sz, i32]),
     "stark_ntt_rows_dev": (i32, [vp, i32, vp, sz, sz, i32, vp]),
+    "stark_ntt_columns_coset_dev": (i32, [vp, i32, vp, sz, sz, sz, sz, vp]),
+    "stark_permute3_dev": (i32, [vp, vp, vp, sz, sz, sz, i32, i32, i32]),
+    "stark_interleave_dev": (i32, [vp, vp, vp, sz, sz, sz]),
+    "stark_comm_unique_id": (i32, [vp]),
+    "stark_comm_init": (i32, [vp, i32, i32, vp]),
+    "stark_comm_destroy": (i32, [vp]),
+    "stark_comm_size": (i32, [vp]),
+    "stark_comm_rank": (i32, [vp]),
+    "stark_comm_all_to_all_dev": (i32, [vp, vp, vp, sz]),
+    "stark_comm_all_gather_dev": (i32, [vp, vp, vp, sz]),
+    "stark_comm_all_reduce_u64_dev": (i32, [vp, vp, vp, sz]),
+    "stark_comm_gather_dev": (i32, [vp, vp, vp, sz, i32]),
     "stark_synth_column_dev": (i32, [vp, u64, u64, sz, sz, vp]),
 }
 

@@ -238,6 +238,7 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (!ctx) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
     (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
+    stark::comm_destroy(ctx);
     stark::ntt_plans_free(ctx);
     if (ctx->tparams) stark_poseidon_params_free(ctx->tparams);
     for (auto& kv : ctx->merkle_params) stark_poseidon_params_free(kv.second);
@@ -279,6 +280,35 @@ int32_t stark_timer_stop_ms(stark_ctx_t* ctx, float* ms) {
     if (!ctx || !ms) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
     STARK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream)); STARK_HIP(ctx, hipEventSynchronize(ctx->ev1)); STARK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1)); return STARK_OK; }
+
+// ---- diagnostics: the integer-VALU "speed of light" of this device, measured live -----------------------
+}  // extern "C"
+// 8 independent v_mad_u64_u32 chains per lane (the primitive of every field product here); 4 waves per SIMD.
+#define STARK_DIAG_ITERS 2048
+static __global__ void __launch_bounds__(1024) k_diag_mac_rate(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 * 9 + 4, a5 = a0 * 11 + 5, a6 = a0 * 13 + 6, a7 = a0 * 15 + 7;
+    uint64_t d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7; const uint32_t b = seed | 1;
+#define STARK_DIAG_MAD(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d##i) : "v"(a##i), "v"(b) : "vcc");
+    for (int i = 0; i < STARK_DIAG_ITERS; ++i) { STARK_DIAG_MAD(0) STARK_DIAG_MAD(1) STARK_DIAG_MAD(2) STARK_DIAG_MAD(3) STARK_DIAG_MAD(4) STARK_DIAG_MAD(5) STARK_DIAG_MAD(6) STARK_DIAG_MAD(7) }
+#undef STARK_DIAG_MAD
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(d0 ^ d1 ^ d2 ^ d3 ^ d4 ^ d5 ^ d6 ^ d7);
+}
+extern "C" {
+int32_t stark_diag_mac_rate(stark_ctx_t* ctx, double* lane_macs_per_s) {
+    if (!ctx || !lane_macs_per_s) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    hipDeviceProp_t prop; STARK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * 2, threads = 1024;        // 2 x 16 waves per CU = 8 waves per SIMD resident, issue-bound either way
+    DevBuf o; STARK_HIP(ctx, o.alloc(ctx, (size_t)blocks * threads * 4));
+    hipLaunchKernelGGL(k_diag_mac_rate, dim3(blocks), dim3(threads), 0, ctx->stream, (uint32_t*)o.p, 12345u);       // warm-up (clocks, code object)
+    STARK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_diag_mac_rate, dim3(blocks), dim3(threads), 0, ctx->stream, (uint32_t*)o.p, 12345u);
+    STARK_HIP(ctx, hipGetLastError());
+    STARK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream)); STARK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0; STARK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *lane_macs_per_s = (double)blocks * threads * 8.0 * STARK_DIAG_ITERS / (ms * 1e-3);
+    return STARK_OK;
+}
 
 // ---- constants ---------------------------------------------------------------------------------------
 int32_t stark_poseidon_params_upload(stark_ctx_t* ctx, int32_t t, int32_t rf, int32_t rp, const uint64_t* mds, const uint64_t* rc_full, const uint64_t* rc_partial, stark_params_t** out) {

@@ -21,7 +21,10 @@ struct NttPlan {
     bool have_coset = false; fr_t coset; DevTable coset_tab;
     // direct tables (log_n <= 24): inter-pass twiddles of the strided passes, coset pre-scale
     fr_t* tw_direct[2] = {nullptr, nullptr}; fr_t* coset_direct = nullptr;
+    // power tables of coset shifts used by the multi-GPU column phase (a handful: the 2^log_blowup cosets of an LDE)
+    std::vector<std::pair<fr_t, DevTable>> shift_tabs;
     ~NttPlan() {
+        for (auto& st : shift_tabs) { if (st.second.lo) (void)hipFree(st.second.lo); if (st.second.hi) (void)hipFree(st.second.hi); }
         for (auto p : tw_direct) if (p) (void)hipFree(p);
         if (coset_direct) (void)hipFree(coset_direct);
         for (auto p : stage_tw) if (p) (void)hipFree(p);
@@ -185,7 +188,7 @@ void stark::ntt_set_attrs() {
 // Multi-GPU phase A: column NTTs of size 2^log_rows over a row-major [2^log_rows][ncols] slab whose first
 // column has global index col0, followed by the twiddle w_N^(col_global * k), N = 2^log_n.  In place.
 template <class F>
-static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t ncols, uint64_t col0, int log_n, bool inverse) {
+static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t ncols, uint64_t col0, int log_n, bool inverse, const fr_t* shift = nullptr) {
     if (log_rows < 1 || log_rows > 10) return ctx->fail(STARK_ERR_UNSUPPORTED, "column NTT size must be 2..1024");
     if (ncols == 0 || (ncols & (ncols - 1))) return ctx->fail(STARK_ERR_INVALID_ARG, "ncols must be a power of two");
     NttPlan* big = nullptr; STARK_TRY(get_plan<F>(ctx, log_n, inverse, &big));        // root table of w_N
@@ -194,6 +197,20 @@ static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t nc
     int log_cols = 0; while ((1ull << log_cols) < ncols) ++log_cols;
     A.log_b = log_rows; A.log_c = pick_log_c(log_rows, log_cols); A.log_n = log_n; A.stride = ncols; A.log_m = log_n;
     A.stage_tw = sm->stage_tw[0]; A.root = big->root.view(); A.rest0 = col0;
+    if (shift && !fr_eq(*shift, fr_one<F>())) {
+        // coset evaluation: x[j] *= shift^j with j the GLOBAL natural index of the element (row * C + global column)
+        if (inverse) return ctx->fail(STARK_ERR_UNSUPPORTED, "column phase: the coset pre-scale belongs to a forward transform");
+        DevTable* T = nullptr;
+        for (auto& st : big->shift_tabs) if (fr_eq(st.first, *shift)) T = &st.second;
+        if (!T) {
+            if (big->shift_tabs.size() >= 32) { STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); auto& old = big->shift_tabs.front(); (void)hipFree(old.second.lo); (void)hipFree(old.second.hi); big->shift_tabs.erase(big->shift_tabs.begin()); }
+            big->shift_tabs.push_back({*shift, DevTable()});
+            const int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
+            STARK_TRY(fill_table<F>(ctx, *shift, fr_one<F>(), lo_bits, hi_bits, big->shift_tabs.back().second));
+            T = &big->shift_tabs.back().second;
+        }
+        A.pre = T->view(); A.pre_row_stride = 1ull << (log_n - log_rows);
+    }
     return launch_strided<F>(ctx, A, (uint64_t)ncols << log_rows, slab, slab);
 }
 extern "C" {
@@ -237,6 +254,31 @@ int32_t stark_ntt_columns_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab
     if (field_id == STARK_FIELD_PALLAS_FR) return columns_run<PallasFr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, inverse != 0);
     if (field_id == STARK_FIELD_BLS12_381_FR) return columns_run<Bls12381Fr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, inverse != 0);
     return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+int32_t stark_ntt_columns_coset_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, const uint64_t* shift4) {
+    if (!ctx || !slab || !shift4) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const fr_t sh = load_fr(shift4);
+    if (field_id == STARK_FIELD_PALLAS_FR) return columns_run<PallasFr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, false, &sh);
+    if (field_id == STARK_FIELD_BLS12_381_FR) return columns_run<Bls12381Fr>(ctx, as_fr(slab), (int)log_rows, ncols, col0, (int)log_n, false, &sh);
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+int32_t stark_permute3_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t d0, size_t d1, size_t d2, int32_t p0, int32_t p1, int32_t p2) {
+    if (!ctx || !src || !dst || src == dst) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const int pm[3] = {p0, p1, p2}; int seen = 0; for (int i = 0; i < 3; ++i) { if (pm[i] < 0 || pm[i] > 2) return ctx->fail(STARK_ERR_INVALID_ARG, "permutation"); seen |= 1 << pm[i]; }
+    if (seen != 7) return ctx->fail(STARK_ERR_INVALID_ARG, "permutation");
+    const uint64_t d[3] = {d0, d1, d2}, st[3] = {(uint64_t)d1 * d2, (uint64_t)d2, 1};
+    const uint64_t tot = (uint64_t)d0 * d1 * d2; if (!tot) return STARK_OK;
+    hipLaunchKernelGGL(k_permute3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, as_fr(src), as_fr(dst), d[pm[0]], d[pm[1]], d[pm[2]], st[pm[0]], st[pm[1]], st[pm[2]]);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+int32_t stark_interleave_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t n, size_t stride, size_t offset) {
+    if (!ctx || !src || !dst || !stride || offset >= stride) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    if (!n) return STARK_OK;
+    hipLaunchKernelGGL(k_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, as_fr(src), as_fr(dst), (uint64_t)n, (uint64_t)stride, (uint64_t)offset);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
 // Multi-GPU phase B: `nrows` contiguous NTTs of size 2^log_cols.  scale4 (optional) multiplies every output
 // (the caller passes N^-1 of the FULL transform for an inverse; the per-row n^-1 is not applied).

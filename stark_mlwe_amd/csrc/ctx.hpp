@@ -26,8 +26,10 @@ struct stark_params {
     stark::PoseidonDev dev{};            // device pointers into `blob`
 };
 
+struct stark_comm;
 struct stark_ctx {
     int device = 0;
+    stark_comm* comm = nullptr;                      // RCCL communicator spanning the ranks (capi_comm.hip); nullptr until stark_comm_init
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side_stream = nullptr;               // lazily created: small independent jobs that run underneath a big one (fri_build)
@@ -107,6 +109,7 @@ int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out);
 int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out);
 int32_t ctx_side_stream(stark_ctx* ctx, hipStream_t* out);
 int32_t ctx_enter(stark_ctx* ctx);                                   // makes the context's device current (every entry point)
+void comm_destroy(stark_ctx* ctx);
 void ntt_set_attrs();                                                // per-device kernel attributes of the NTT kernels (capi_ntt.hip)
 void ntt_plans_free(stark_ctx* ctx);
 int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const fr_t* f_next, size_t n, size_t m, fr_t* h);

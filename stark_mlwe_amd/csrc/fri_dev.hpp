@@ -135,6 +135,20 @@ static __global__ void k_gather(const fr_t* __restrict__ src, const uint64_t* __
     if (i < k) stg(out + i, ldg(src + idx[i]));
 }
 
+// dst[a][b][c] (contiguous, dims Da x Db x Dc) = src[a*sa + b*sb + c*sc]: the layout changes around the all-to-all exchanges
+// of the six-step NTT (32-byte elements, so even the transposing cases move whole 32-B units).
+static __global__ void k_permute3(const fr_t* __restrict__ src, fr_t* __restrict__ dst, uint64_t Da, uint64_t Db, uint64_t Dc, uint64_t sa, uint64_t sb, uint64_t sc) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Da * Db * Dc) return;
+    const uint64_t c = i % Dc, b = (i / Dc) % Db, a = i / (Dc * Db);
+    stg(dst + i, ldg(src + a * sa + b * sb + c * sc));
+}
+// dst[k * stride + offset] = src[k]: interleaves the `stride` coset transforms of an LDE into natural order.
+static __global__ void k_interleave(const fr_t* __restrict__ src, fr_t* __restrict__ dst, uint64_t n, uint64_t stride, uint64_t offset) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) stg(dst + k * stride + offset, ldg(src + k));
+}
+
 // Synthetic column: limb j of element i = mix64(seed + (col << 56) + 4*i + j), top limb masked to 62
 // bits; the limbs are the stored (Montgomery) representation.  (DESIGN.md "Synthetic inputs".)
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {

@@ -47,6 +47,8 @@ struct NttPassArgs {
     // Direct tables (plans up to 2^24 points): one product per element instead of the two of the two-level lookup.
     const fr_t* tw_direct;   // strided pass: w_m^(rest*k) at index k*stride + rest (the layout of the sub-problem); nullptr => `root` lookup
     const fr_t* pre_direct;  // first pass: g^j at index j; nullptr => `pre` lookup
+    uint64_t pre_row_stride; // != 0 (multi-GPU column slabs): the pre-scale exponent of tile element (p, column) is the GLOBAL natural index
+                             // p * pre_row_stride + rest0 + column, not the position inside the local slab
 };
 
 __device__ __forceinline__ fr_t lds_ld(const uint4* lo, const uint4* hi, int slot) {
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttP
         const uint64_t g = base + (uint64_t)p * A.stride + c;
         fr_t x = ldg(src + g);
         if (A.pre_direct) x = fr_mul<F>(x, ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1))));
-        else if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, g));
+        else if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, A.pre_row_stride ? (uint64_t)p * A.pre_row_stride + A.rest0 + (tile << A.log_c) + c : g));
         lds_st(dlo, dhi, idx, x);
     }
     __syncthreads();
