@@ -130,6 +130,10 @@ def main():
         sharding = "one GPU holds the whole trace"
     else:
         from stark_mlwe_amd import dist as sd
+        if backend == "nccl" and os.environ.get("STARK_COMM", "lib") == "lib":
+            # data-path collectives through the library's own RCCL communicator, on the shared stream (include/stark_mlwe.h
+            # stark_comm_*); torch.distributed only carried the unique id and brackets the timed region
+            sd.set_comm(sd.LibComm(ctx, rank, world))
         job = sd.ShardedTrace(sd.HipProvider(ctx, device=dev), log_n + (world.bit_length() - 1), LOG_BLOWUP, SCHEDULE, SEED_Z, coset, z)
 
         def step():
@@ -286,6 +290,22 @@ def _cpu_model():
     return "unknown"
 
 
+def _usable_cores():
+    """Host threads this process may really use: the affinity mask, capped by the cgroup CPU quota of the box's share."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(np, log_n_gpu):
     """The oracle (CPU port of the reference's algorithm, dense MDS as in the reference, constants hoisted) on bounded samples
     of the same work, on this box's host cores: single thread (the reference is single-threaded) and all cores (OpenMP over
@@ -293,8 +313,8 @@ def cpu_baseline(np, log_n_gpu):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     o = oracle_lib.Oracle()
-    ncores = os.cpu_count() or 1
-    res = {"unit": "trace rows/s", "kind": "port", "cpu_model": _cpu_model(), "nproc": ncores, "compiler": "g++ -O2 -fopenmp (oracle/Makefile)"}
+    ncores = _usable_cores()
+    res = {"unit": "trace rows/s", "kind": "port", "cpu_model": _cpu_model(), "nproc": os.cpu_count(), "threads_all_cores_mode": ncores, "compiler": "g++ -O2 -fopenmp (oracle/Makefile)"}
 
     def workload(lg, threads):
         o.l.oracle_set_threads(threads)

@@ -28,45 +28,147 @@ import torch
 import torch.distributed as dist
 
 
+class TorchComm:
+    """Collectives through torch.distributed: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests / one-GPU rehearsals
+    (gloo stages device tensors through host memory)."""
+
+    def world(self):
+        return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+    def all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        rank, W = self.world()
+        if W == 1:
+            return send.clone()
+        recv = torch.empty_like(send)
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1))     # RCCL: one message per peer link
+            return recv
+        # gloo has no all_to_all: W-1 point-to-point pairs, staged through host memory (tests / one-GPU rehearsal only)
+        hs = send.cpu() if send.is_cuda else send
+        hr = torch.empty_like(hs)
+        hr[rank].copy_(hs[rank])
+        ops = []
+        for p in range(W):
+            if p != rank:
+                ops.append(dist.P2POp(dist.isend, hs[p].contiguous(), p))
+                ops.append(dist.P2POp(dist.irecv, hr[p], p))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        recv.copy_(hr)
+        return recv
+
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        rank, W = self.world()
+        if W == 1:
+            return x.clone()
+        if dist.get_backend() == "nccl" and not x.is_cuda:      # RCCL moves device memory only
+            return self.all_gather(x.cuda()).cpu()
+        if dist.get_backend() != "nccl" and x.is_cuda:     # gloo: stage through host memory
+            hx = x.cpu(); out = [torch.empty_like(hx) for _ in range(W)]
+            dist.all_gather(out, hx.contiguous())
+            return torch.cat(out, dim=0).to(x.device)
+        out = [torch.empty_like(x) for _ in range(W)]
+        dist.all_gather(out, x.contiguous())
+        return torch.cat(out, dim=0)
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        rank, W = self.world()
+        if W == 1:
+            return t
+        if dist.get_backend() == "nccl":
+            d = t.cuda() if not t.is_cuda else t.clone()
+            dist.all_reduce(d)
+            return d if t.is_cuda else d.cpu()
+        h = t.cpu().contiguous(); dist.all_reduce(h)
+        return h.to(t.device) if t.is_cuda else h
+
+    def gather_to(self, x: torch.Tensor, dst: int):
+        rank, W = self.world()
+        if W == 1:
+            return x
+        if dist.get_backend() != "nccl" and x.is_cuda:
+            hx = x.cpu(); parts = [torch.empty_like(hx) for _ in range(W)] if rank == dst else None
+            dist.gather(hx, parts, dst=dst)
+            return torch.cat(parts, dim=0).to(x.device) if rank == dst else None
+        parts = [torch.empty_like(x) for _ in range(W)] if rank == dst else None
+        dist.gather(x.contiguous(), parts, dst=dst)
+        return torch.cat(parts, dim=0) if rank == dst else None
+
+
+class LibComm:
+    """Collectives through the library's own RCCL communicator (stark_comm_*, include/stark_mlwe.h): enqueued on the
+    context's stream, no host synchronisation, usable by a host that has no torch.  torch.distributed is needed only to hand
+    the 128-byte unique id from rank 0 to its peers (any transport would do)."""
+
+    def __init__(self, ctx, rank=None, nranks=None):
+        import numpy as np
+        self.ctx, self.lib = ctx, ctx.lib
+        if rank is None:
+            rank, nranks = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        self.rank, self.W = rank, nranks
+        idb = np.zeros(128, np.uint8)
+        if rank == 0:
+            ctx._chk(self.lib.stark_comm_unique_id(idb.ctypes.data_as(C.c_void_p)))
+        if nranks > 1:
+            obj = [idb.tobytes()]
+            dist.broadcast_object_list(obj, src=0)
+            idb = np.frombuffer(obj[0], np.uint8).copy()
+        ctx._chk(self.lib.stark_comm_init(ctx.h, nranks, rank, idb.ctypes.data_as(C.c_void_p)))
+
+    def world(self):
+        return self.rank, self.W
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def all_to_all(self, send):
+        send = send.contiguous(); recv = torch.empty_like(send)
+        self.ctx._chk(self.lib.stark_comm_all_to_all_dev(self.ctx.h, self._p(send), self._p(recv), send.numel() * send.element_size() // self.W))
+        return recv
+
+    def all_gather(self, x):
+        dev = x if x.is_cuda else x.cuda()
+        dev = dev.contiguous(); out = torch.empty((self.W * dev.shape[0],) + tuple(dev.shape[1:]), dtype=dev.dtype, device=dev.device)
+        self.ctx._chk(self.lib.stark_comm_all_gather_dev(self.ctx.h, self._p(dev), self._p(out), dev.numel() * dev.element_size()))
+        return out if x.is_cuda else out.cpu()
+
+    def all_reduce_sum(self, t):
+        d = (t if t.is_cuda else t.cuda()).contiguous().clone()
+        self.ctx._chk(self.lib.stark_comm_all_reduce_u64_dev(self.ctx.h, self._p(d), self._p(d), d.numel() * d.element_size() // 8))
+        return d if t.is_cuda else d.cpu()
+
+    def gather_to(self, x, dst):
+        x = x.contiguous()
+        out = torch.empty((self.W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) if self.rank == dst else None
+        self.ctx._chk(self.lib.stark_comm_gather_dev(self.ctx.h, self._p(x), None if out is None else self._p(out), x.numel() * x.element_size(), dst))
+        return out
+
+    def close(self):
+        self.lib.stark_comm_destroy(self.ctx.h)
+
+
+_COMM = TorchComm()
+
+
+def set_comm(comm):
+    """Route every collective of this module through `comm` (TorchComm by default; LibComm for the library's RCCL)."""
+    global _COMM
+    _COMM = comm if comm is not None else TorchComm()
+    return _COMM
+
+
 def world():
-    return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    return _COMM.world()
 
 
 def exchange_all_to_all(send: torch.Tensor) -> torch.Tensor:
     """send: [W, chunk...] — chunk q goes to rank q.  Returns recv with chunk p = what rank p sent here."""
-    rank, W = world()
-    if W == 1:
-        return send.clone()
-    recv = torch.empty_like(send)
-    if dist.get_backend() == "nccl":
-        dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1))     # RCCL: one message per peer link
-        return recv
-    # gloo has no all_to_all: W-1 point-to-point pairs, staged through host memory (tests / one-GPU rehearsal only)
-    hs = send.cpu() if send.is_cuda else send
-    hr = torch.empty_like(hs)
-    hr[rank].copy_(hs[rank])
-    ops = []
-    for p in range(W):
-        if p != rank:
-            ops.append(dist.P2POp(dist.isend, hs[p].contiguous(), p))
-            ops.append(dist.P2POp(dist.irecv, hr[p], p))
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
-    recv.copy_(hr)
-    return recv
+    return _COMM.all_to_all(send)
 
 
 def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
-    rank, W = world()
-    if W == 1:
-        return x.clone()
-    if dist.get_backend() != "nccl" and x.is_cuda:     # gloo: stage through host memory
-        hx = x.cpu(); out = [torch.empty_like(hx) for _ in range(W)]
-        dist.all_gather(out, hx.contiguous())
-        return torch.cat(out, dim=0).to(x.device)
-    out = [torch.empty_like(x) for _ in range(W)]
-    dist.all_gather(out, x.contiguous())
-    return torch.cat(out, dim=0)
+    return _COMM.all_gather(x)
 
 
 class HipProvider:
@@ -104,6 +206,25 @@ class HipProvider:
     def ntt_rows(self, slab, nrows, log_cols, inverse, scale4=None):
         from .api import _ptr
         self._run(self.lib.stark_ntt_rows_dev, self.ctx.h, self.field, self._p(slab), nrows, log_cols, int(inverse), _ptr(scale4))
+
+    def ntt_columns_coset(self, slab, log_rows, ncols, col0, log_n, shift4):
+        self._run(self.lib.stark_ntt_columns_coset_dev, self.ctx.h, self.field, self._p(slab), log_rows, ncols, col0, log_n, _npp(shift4))
+
+    def permute3(self, src, dims, perm):
+        """Contiguous [dims[perm[0]], dims[perm[1]], dims[perm[2]], 4] copy of the [d0][d1][d2] array `src` (hand-written pack kernel)."""
+        out = torch.empty((dims[perm[0]] * dims[perm[1]] * dims[perm[2]], 4), dtype=torch.int64, device=src.device)
+        self._run(self.lib.stark_permute3_dev, self.ctx.h, self._p(src), self._p(out), dims[0], dims[1], dims[2], perm[0], perm[1], perm[2])
+        return out
+
+    def interleave(self, dst, src, stride, offset):
+        self._run(self.lib.stark_interleave_dev, self.ctx.h, self._p(src), self._p(dst), src.shape[0], stride, offset)
+
+    def pow_small(self, base_int, e):
+        """Montgomery limbs of base^e in the provider's field (host scalar)."""
+        return _mont(pow(base_int, e, _P[self.field]), self.field)
+
+    def root_of_unity(self, log_n):
+        return _mont(pow(_GEN[self.field], (_P[self.field] - 1) >> log_n, _P[self.field]), self.field)
 
     def merkle_build(self, params, arity, tree_label, leaves, n, first_pos, level0, stop_at_len):
         h = C.c_void_p()
@@ -186,6 +307,21 @@ class HipProvider:
         return self.ctx.fri_query_plan(roots, n0, schedule, r)
 
 
+_P = {0: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001, 1: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001}
+_GEN = {0: 5, 1: 7}          # multiplicative generators
+
+
+def _mont(x, field=0):
+    import numpy as np
+    m = (x << 256) % _P[field]
+    return np.array([(m >> (64 * i)) & (2**64 - 1) for i in range(4)], np.uint64)
+
+
+def _unmont(a, field=0):
+    v = sum(int(a[i]) << (64 * i) for i in range(4))
+    return v * pow(1 << 256, -1, _P[field]) % _P[field]
+
+
 def _npp(a):
     import numpy as np
     a = np.ascontiguousarray(a, dtype=np.uint64)
@@ -220,16 +356,23 @@ class DistNtt:
         kp = torch.arange(self.C).view(1, -1)
         return k1 + self.R * kp
 
-    def forward(self, slab: torch.Tensor, scale4=None) -> torch.Tensor:
-        """slab: [R * C/W, 4] (row-major [R][C/W]).  Returns [R/W * C, 4] (row-major [R/W][C])."""
+    def _perm(self, t, dims, perm):
+        if hasattr(self.p, "permute3"):
+            return self.p.permute3(t, dims, perm)
+        return t.view(*dims, 4).permute(*perm, 3).contiguous().view(-1, 4)
+
+    def forward(self, slab: torch.Tensor, scale4=None, shift4=None) -> torch.Tensor:
+        """slab: [R * C/W, 4] (row-major [R][C/W]).  Returns [R/W * C, 4] (row-major [R/W][C]).
+        shift4 (forward only): evaluate on the coset shift * <w> (x[j] *= shift^j on load, j the natural index)."""
         R, ncl, nrl, W = self.R, self.ncl, self.nrl, self.W
         # phase A: column NTTs of size R on the local column block + twiddle w_N^(col_global * k1)
-        self.p.ntt_columns(slab, self.log_rows, ncl, self.rank * ncl, self.log_n, self.inverse)
-        # the one exchange: rows k1 of block q go to rank q (contiguous [R/W][C/W] chunks of the slab)
-        send = slab.view(W, nrl * ncl, 4)
-        self.p.sync()
-        recv = exchange_all_to_all(send)                                          # [W(src p), R/W, C/W]
-        rows = recv.view(W, nrl, ncl, 4).permute(1, 0, 2, 3).contiguous().view(nrl * self.C, 4)
+        if shift4 is not None:
+            self.p.ntt_columns_coset(slab, self.log_rows, ncl, self.rank * ncl, self.log_n, shift4)
+        else:
+            self.p.ntt_columns(slab, self.log_rows, ncl, self.rank * ncl, self.log_n, self.inverse)
+        # the one exchange: rows k1 of block q go to rank q (contiguous [R/W][C/W] chunks of the slab); stream-ordered, no host sync
+        recv = exchange_all_to_all(slab.view(W, nrl * ncl, 4))                   # [W(src p), R/W, C/W]
+        rows = self._perm(recv.view(-1, 4), (W, nrl, ncl), (1, 0, 2))             # [R/W][W][C/W] = [R/W][C]
         # phase B: R/W contiguous NTTs of size C
         self.p.ntt_rows(rows, nrl, self.log_n - self.log_rows, self.inverse, scale4)
         return rows
@@ -238,9 +381,49 @@ class DistNtt:
         """Second all-to-all: from the transposed output to natural order, block-sharded (n/W contiguous)."""
         W, nrl, Cc = self.W, self.nrl, self.C
         # rank q holds X[k1 + R*k'] for its k1 block; natural block b holds k in [b*n/W, (b+1)*n/W) <=> k' in [b*C/W, (b+1)*C/W)
-        send = rows.view(nrl, W, Cc // W, 4).permute(1, 2, 0, 3).contiguous()   # [dst b][k' local][k1 local]
-        recv = exchange_all_to_all(send.view(W, -1, 4))                          # [src q][k' local][k1 local]
-        return recv.view(W, Cc // W, nrl, 4).permute(1, 0, 2, 3).contiguous().view(-1, 4)   # [k' local][k1 global]
+        send = self._perm(rows, (nrl, W, Cc // W), (1, 2, 0))                     # [dst b][k' local][k1 local]
+        recv = exchange_all_to_all(send.view(W, -1, 4))                           # [src q][k' local][k1 local]
+        return self._perm(recv.view(-1, 4), (W, Cc // W, nrl), (1, 0, 2))         # [k' local][k1 global]
+
+    def from_natural_blocks(self, block: torch.Tensor) -> torch.Tensor:
+        """Natural-order block [n/W] (= rows j1 in [rank*R/W, (rank+1)*R/W) of the [R][C] view) -> the input slab [R][C/W]."""
+        W, nrl, ncl = self.W, self.nrl, self.ncl
+        send = self._perm(block, (nrl, W, ncl), (1, 0, 2))                        # [dst r][j1 local][c]
+        recv = exchange_all_to_all(send.view(W, -1, 4))                           # [src p][j1 local][c] = [R][C/W]
+        return recv.view(-1, 4)
+
+
+class ShardedLde:
+    """LDE of ONE column of n = 2^log_n evaluations (natural order, block-sharded: rank q holds [q*n/W, (q+1)*n/W)) to
+    N = n * 2^log_blowup evaluations on shift * <w_N>, natural order, block-sharded again.
+        coefficients  c = iNTT_n(evals)                                   (six-step, one transpose)
+        out[b*k + s]  = NTT_n(c[j] * (shift * w_N^s)^j)[k],  s < b = 2^log_blowup     (b coset transforms of size n: the zero
+                                                                            padding of the definition is never materialised)
+    Every transform is a `DistNtt`; between them only layout changes (all-to-all + pack kernels)."""
+
+    def __init__(self, provider, log_n, log_blowup, shift_int=5, log_rows=None):
+        self.p, self.log_n, self.lb = provider, log_n, log_blowup
+        self.rank, self.W = world()
+        self.inv = DistNtt(provider, log_n, log_rows, inverse=True)
+        self.fwd = DistNtt(provider, log_n, log_rows, inverse=False)
+        fld = getattr(provider, "field", 0)
+        P = _P[fld]
+        wN = pow(_GEN[fld], (P - 1) >> (log_n + log_blowup), P)
+        self.shifts = [_mont(shift_int * pow(wN, s_, P) % P, fld) for s_ in range(1 << log_blowup)]
+        self.ninv = _mont(pow(1 << log_n, -1, P), fld)
+        self.n_all_to_all = 3 + 2 * (1 << log_blowup)
+
+    def __call__(self, block: torch.Tensor) -> torch.Tensor:
+        b = 1 << self.lb
+        coeff_rows = self.inv.forward(self.inv.from_natural_blocks(block), self.ninv)      # coefficients, transposed block order
+        coeff = self.inv.to_natural_blocks(coeff_rows)
+        slab0 = self.fwd.from_natural_blocks(coeff)                                        # input layout of the forward transforms
+        out = self.p.new(block.shape[0] * b)
+        for s_ in range(b):
+            slab = slab0.clone() if s_ + 1 < b else slab0
+            y = self.fwd.to_natural_blocks(self.fwd.forward(slab, None, self.shifts[s_]))
+            self.p.interleave(out, y, b, s_)
+        return out
 
 
 def sharded_stop_len(n_local: int, arity: int) -> int:
@@ -290,26 +473,12 @@ def hashed_arity(a):
 
 def _allreduce_sum(t: torch.Tensor) -> torch.Tensor:
     """Sum of int64 tables in which every row is non-zero on exactly one rank (so the sum is a selection)."""
-    rank, W = world()
-    if W == 1:
-        return t
-    if dist.get_backend() == "nccl":
-        d = t.cuda(); dist.all_reduce(d); return d.cpu()
-    h = t.cpu().contiguous(); dist.all_reduce(h); return h
+    return _COMM.all_reduce_sum(t)
 
 
 def _gather_to(x: torch.Tensor, dst: int):
     """Concatenation of every rank's block on rank dst (None elsewhere)."""
-    rank, W = world()
-    if W == 1:
-        return x
-    if dist.get_backend() != "nccl" and x.is_cuda:
-        hx = x.cpu(); parts = [torch.empty_like(hx) for _ in range(W)] if rank == dst else None
-        dist.gather(hx, parts, dst=dst)
-        return torch.cat(parts, dim=0).to(x.device) if rank == dst else None
-    parts = [torch.empty_like(x) for _ in range(W)] if rank == dst else None
-    dist.gather(x.contiguous(), parts, dst=dst)
-    return torch.cat(parts, dim=0) if rank == dst else None
+    return _COMM.gather_to(x, dst)
 
 
 class _Layer:
@@ -498,3 +667,31 @@ class DistProver:
         self.timings = {"build_f0_ms": (t1 - t0) * 1e3, "fri_build_ms": (t2 - t1) * 1e3, "queries_encode_ms": (t3 - t2) * 1e3}
         self.free()
         return out
+
+
+class ShardedTrace:
+    """The bench workload for N > 1 (BASELINE configs[3]/[4] shape): ONE trace of 2^log_n rows x 4 columns, natural-order
+    blocks over the ranks; one step = sharded LDE of the four columns (six-step NTTs, all-to-all transposes), block-local
+    DEEP-ALI merge with global indices, and the sharded commit phase of `DistProver` (folds, leaf hashes, lower Merkle levels
+    block-local; tree tops all-gathered).  Returns the L+1 roots — the same values a single GPU computes for the whole trace."""
+
+    def __init__(self, provider, log_n, log_blowup, schedule, seed_z, coset4, z4):
+        self.p, self.log_n, self.lb = provider, log_n, log_blowup
+        self.rank, self.W = world()
+        self.lde = ShardedLde(provider, log_n, log_blowup, _unmont(coset4, getattr(provider, "field", 0)))
+        self.z4 = z4
+        self.N = 1 << (log_n + log_blowup)
+        self.prover = DistProver(provider, self.N, schedule, 1, seed_z)
+
+    def describe(self):
+        return (f"one trace block-sharded over {self.W} ranks: LDE = {self.lde.n_all_to_all} all-to-all exchanges per column "
+                f"(six-step NTT transposes, {type(_COMM).__name__}), merge / folds / leaf hashes / lower Merkle levels block-local, tree tops all-gathered")
+
+    def step(self, cols):
+        ext = [self.lde(c) for c in cols]
+        nl = self.N // self.W
+        f0 = self.p.ali_merge_shard(ext[0], ext[1], ext[2], ext[3], self.z4, self.rank * nl, self.N)
+        del ext
+        roots = self.prover.commit(f0)
+        self.prover.free()
+        return [roots[l] for l in range(roots.shape[0])]

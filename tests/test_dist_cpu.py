@@ -37,6 +37,18 @@ class CpuStandIn:
             for k in range(1 << log_rows):
                 a[k, c, :] = self.o.mul(col[k], tw, self.field); tw = self.o.mul(tw, wc, self.field)
 
+    def ntt_columns_coset(self, slab, log_rows, ncols, col0, log_n, shift4):
+        # x[j] *= shift^j with j = row * C + global column, then the plain forward column phase
+        a = self._np(slab).reshape(1 << log_rows, ncols, 4); C = 1 << (log_n - log_rows)
+        for c in range(ncols):
+            base = self.o.pow(shift4, col0 + c, self.field); step = self.o.pow(shift4, C, self.field); cur = base
+            for r in range(1 << log_rows):
+                a[r, c, :] = self.o.mul(a[r, c, :], cur, self.field); cur = self.o.mul(cur, step, self.field)
+        self.ntt_columns(slab, log_rows, ncols, col0, log_n, False)
+
+    def interleave(self, dst, src, stride, offset):
+        dst.view(-1, stride, 4)[:, offset, :] = src
+
     def ntt_rows(self, slab, nrows, log_cols, inverse, scale4=None):
         a = self._np(slab).reshape(nrows, 1 << log_cols, 4)
         for r in range(nrows):
@@ -175,6 +187,51 @@ def test_sharded_prove_world2_matches_reference_bytes(log_n0, schedule, r):
     res = [q.get(timeout=400) for _ in procs]
     for p in procs: p.join(60)
     assert sorted(res) == [(0, True, True, 1), (1, True, True, 1)], res
+
+
+def _lde_worker(rank, world, port, log_n, log_rows, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stark_mlwe_amd import dist as sd
+        prov = CpuStandIn(); o = prov.o
+        n, lb = 1 << log_n, 2
+        nl = n // world
+        ev = o.synth_column(77, 0, 0, n)
+        lde = sd.ShardedLde(prov, log_n, lb, 5, log_rows)
+        out = lde(prov._t(ev[rank * nl:(rank + 1) * nl])).numpy().view(np.uint64)
+        want = o.lde(0, ev, lb, o.from_u64(5))
+        ok_lde = bool((out == want[rank * nl * 4:(rank + 1) * nl * 4]).all())
+        # the chained bench step: LDE of four columns -> merge -> sharded commit; roots must equal the oracle's for the whole trace
+        cols = [o.synth_column(78, c, 0, n) for c in range(4)]
+        z = o.from_u64(0xC0FFEE); coset = o.from_u64(5); sched = [8, 4]
+        job = sd.ShardedTrace(prov, log_n, lb, sched, 0xDEEFBAAD, coset, z)
+        roots = job.step([prov._t(c[rank * nl:(rank + 1) * nl]) for c in cols])
+        ext = [o.lde(0, c, lb, coset) for c in cols]
+        f0, _ = o.ali_merge(ext[0], ext[1], ext[2], ext[3], o.domain_omega(n << lb), z, want_c_star=False)
+        ref = o.deep_fri_prove(None, None, None, None, n << lb, sched, 1, 0xDEEFBAAD, f0=f0)
+        ok_roots = all(bool((np.asarray(roots[l]).view(np.uint64).reshape(4) == ref.root(l)).all()) for l in range(len(sched) + 1)); ref.free()
+        q.put((rank, ok_lde, ok_roots, "all-to-all" in job.describe()))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        q.put(("error", repr(ex), traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("log_n,log_rows", [(7, 3), (8, 4)])
+def test_sharded_lde_and_chained_step_world2(log_n, log_rows):
+    """north_star's multi-GPU split on 2 ranks (gloo): the LDE of a block-sharded column through the six-step NTTs equals the
+    oracle's LDE of the whole column, and LDE -> merge -> sharded commit gives the oracle's roots for the whole trace."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + log_n
+    procs = [ctx.Process(target=_lde_worker, args=(r_, 2, port, log_n, log_rows, q)) for r_ in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs: p.join(60)
+    assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
 
 
 def test_sharded_stop_len():

@@ -199,3 +199,67 @@ def test_pooled_allocator_reuses_blocks_and_trims(gpu_ctx, oracle):
     assert all((ref.root(l) == r1[l]).all() for l in range(4)); ref.free()
     gpu_ctx.trim()
     assert gpu_ctx.lib.stark_ctx_cached_bytes(gpu_ctx.h) == 0
+
+
+# ---- multi-GPU split, rehearsed on the one GPU ---------------------------------------------------------------------------
+def test_library_rccl_communicator_one_rank(gpu_ctx):
+    """stark_comm_* (RCCL bound at run time) on a one-rank communicator: the exact calls the N > 1 bench makes (all-to-all of
+    the six-step transpose, all-gather of tree tops, u64 all-reduce of the query table, gather of a column), on the context's
+    stream, with int64 limb tensors."""
+    import torch
+    from stark_mlwe_amd import dist as sd
+    comm = sd.LibComm(gpu_ctx, 0, 1)
+    try:
+        assert gpu_ctx.lib.stark_comm_size(gpu_ctx.h) == 1 and gpu_ctx.lib.stark_comm_rank(gpu_ctx.h) == 0
+        x = (torch.arange(4 * 64 * 4, dtype=torch.int64, device="cuda") * 0x9E3779B97F4A7C15 % (1 << 62)).view(4 * 64, 4)
+        assert bool((comm.all_to_all(x.view(1, -1, 4)).view(-1, 4) == x).all())
+        assert bool((comm.all_gather(x) == x).all())
+        assert bool((comm.all_reduce_sum(x) == x).all())
+        assert bool((comm.all_reduce_sum(x.cpu()) == x.cpu()).all())
+        assert bool((comm.gather_to(x, 0) == x).all())
+        gpu_ctx.sync()
+    finally:
+        comm.close()
+    # without a communicator the data-path calls fail loudly
+    import torch
+    y = torch.zeros((4, 4), dtype=torch.int64, device="cuda"); z2 = torch.zeros_like(y)
+    assert gpu_ctx.lib.stark_comm_all_to_all_dev(gpu_ctx.h, C.c_void_p(y.data_ptr()), C.c_void_p(z2.data_ptr()), 128) == -3      # STARK_ERR_RCCL
+
+
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_sharded_trace_world1_equals_single_gpu_step(gpu_ctx, oracle, log_n):
+    """The N > 1 bench step (ShardedLde = 2^b coset transforms through the six-step building blocks + pack kernels, shard merge,
+    sharded commit) on ONE rank through the library's communicator must give the roots of the single-GPU step (stark_lde_dev,
+    stark_ali_merge_dev, stark_fri_build_dev) — and, at 2^12, the oracle's."""
+    import torch
+    import bench
+    from stark_mlwe_amd import dist as sd
+    from stark_mlwe_amd.api import _ptr
+    lb, sched = 3, [16, 16, 8]
+    n, N = 1 << log_n, 1 << (log_n + lb)
+    cols = _dev_cols(gpu_ctx, 0x5EED0000 + log_n, n)
+    coset, z, omega = bench._mont_small(5), bench._mont_small(0xC0FFEE), bench._root_of_unity_pallas(log_n + lb)
+    comm = sd.set_comm(sd.LibComm(gpu_ctx, 0, 1))
+    try:
+        job = sd.ShardedTrace(sd.HipProvider(gpu_ctx), log_n, lb, sched, SEED_Z, coset, z)
+        roots = job.step(cols)
+        # sharded LDE alone against the library's single-GPU LDE
+        ext_sh = job.lde(cols[1]); ext = torch.empty((N, 4), dtype=torch.int64, device="cuda")
+        gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, PALLAS_FR, C.c_void_p(cols[1].data_ptr()), log_n, lb, _ptr(coset), C.c_void_p(ext.data_ptr())))
+        assert bool((ext_sh == ext).all())
+    finally:
+        sd.set_comm(None); comm.close()
+    exts = [torch.empty((N, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+    for c in range(4):
+        gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, PALLAS_FR, C.c_void_p(cols[c].data_ptr()), log_n, lb, _ptr(coset), C.c_void_p(exts[c].data_ptr())))
+    f0 = torch.empty((N, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx._chk(gpu_ctx.lib.stark_ali_merge_dev(gpu_ctx.h, *[C.c_void_p(e.data_ptr()) for e in exts], None, None, _ptr(omega), _ptr(z), N, C.c_void_p(f0.data_ptr()), None))
+    st = C.c_void_p(); sch = np.ascontiguousarray(sched, dtype=np.uint64)
+    gpu_ctx._chk(gpu_ctx.lib.stark_fri_build_dev(gpu_ctx.h, C.c_void_p(f0.data_ptr()), N, _ptr(sch), 3, SEED_Z, C.byref(st)))
+    for l in range(4):
+        r = np.zeros(4, np.uint64); gpu_ctx._chk(gpu_ctx.lib.stark_fri_layer_root(st, l, _ptr(r)))
+        assert (np.asarray(roots[l]).view(np.uint64).reshape(4) == r).all(), f"layer {l}"
+    gpu_ctx._chk(gpu_ctx.lib.stark_fri_state_free(st))
+    if log_n <= 12:
+        ref = oracle.deep_fri_prove(None, None, None, None, N, sched, 1, SEED_Z, f0=f0.cpu().numpy().view(np.uint64))
+        assert all((ref.root(l) == np.asarray(roots[l]).view(np.uint64).reshape(4)).all() for l in range(4)); ref.free()

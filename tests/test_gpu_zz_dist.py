@@ -132,6 +132,62 @@ def test_sharded_prove_two_ranks_one_gpu(log_n0, schedule, r):
     assert sorted(res) == [(0, True, True, want_oracle, 1), (1, True, True, want_oracle, 1)], res
 
 
+def _trace_worker(rank, world, port, log_n, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    _rendezvous_env(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        import bench, oracle_lib
+        from stark_mlwe_amd import dist as sd
+        from stark_mlwe_amd.api import Context, PALLAS_FR, _ptr
+        torch.cuda.set_device(0)
+        ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+        ctx = Context(0, C.c_void_p(ts.cuda_stream)); lib = ctx.lib
+        lb, sched = 3, [16, 16, 8]
+        n_tot = 1 << log_n; nl = n_tot // world; N = n_tot << lb
+        coset, z, omega = bench._mont_small(5), bench._mont_small(0xC0FFEE), bench._root_of_unity_pallas(log_n + lb)
+        mine = [torch.empty((nl, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+        whole = [torch.empty((n_tot, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+        for c in range(4):
+            ctx._chk(lib.stark_synth_column_dev(ctx.h, 0x5EED0000 + log_n, c, rank * nl, nl, C.c_void_p(mine[c].data_ptr())))
+            ctx._chk(lib.stark_synth_column_dev(ctx.h, 0x5EED0000 + log_n, c, 0, n_tot, C.c_void_p(whole[c].data_ptr())))
+        job = sd.ShardedTrace(sd.HipProvider(ctx, device=torch.device("cuda", 0)), log_n, lb, sched, 0xDEEFBAAD, coset, z)
+        roots = job.step(mine)
+        # the one-GPU path over the whole trace
+        exts = [torch.empty((N, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+        for c in range(4):
+            ctx._chk(lib.stark_lde_dev(ctx.h, PALLAS_FR, C.c_void_p(whole[c].data_ptr()), log_n, lb, _ptr(coset), C.c_void_p(exts[c].data_ptr())))
+        f0 = torch.empty((N, 4), dtype=torch.int64, device="cuda")
+        ctx._chk(lib.stark_ali_merge_dev(ctx.h, *[C.c_void_p(e.data_ptr()) for e in exts], None, None, _ptr(omega), _ptr(z), N, C.c_void_p(f0.data_ptr()), None))
+        st = C.c_void_p(); sch = np.ascontiguousarray(sched, dtype=np.uint64)
+        ctx._chk(lib.stark_fri_build_dev(ctx.h, C.c_void_p(f0.data_ptr()), N, _ptr(sch), 3, 0xDEEFBAAD, C.byref(st)))
+        ok = True
+        for l in range(4):
+            r = np.zeros(4, np.uint64); ctx._chk(lib.stark_fri_layer_root(st, l, _ptr(r)))
+            ok = ok and bool((np.asarray(roots[l]).view(np.uint64).reshape(4) == r).all())
+        ctx._chk(lib.stark_fri_state_free(st)); ctx.close()
+        q.put((rank, ok))
+    except Exception as ex:      # noqa: BLE001 — report instead of leaving the parent waiting
+        import traceback
+        q.put(("error", repr(ex), traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("log_n", [14, 18])
+def test_sharded_trace_two_ranks_one_gpu(log_n):
+    """The N > 1 bench step on 2 ranks sharing the GPU (gloo exchange): sharded LDE (six-step NTTs with real rank offsets, pack
+    kernels), shard merge and sharded commit give the roots of the one-GPU step over the whole trace."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30300 + (os.getpid() % 1000) + log_n
+    procs = [ctx.Process(target=_trace_worker, args=(r_, 2, port, log_n, q)) for r_ in range(2)]
+    for p in procs: p.start()
+    res = _collect(procs, q, 2, "sharded trace step")
+    assert sorted(res) == [(0, True), (1, True)], res
+
+
 def _rccl_worker(port, q):
     _rendezvous_env(port)
     torch.cuda.set_device(0)
