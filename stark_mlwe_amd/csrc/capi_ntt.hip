@@ -118,7 +118,7 @@ static int32_t launch_last(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, 
 
 // `batch` vectors of 2^log_n elements each, contiguous.  data is transformed in place (scratch from the context).
 template <class F>
-static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bool inverse, const fr_t* coset, const fr_t* scale_override_dev) {
+static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bool inverse, const fr_t* coset, const fr_t* scale_override_dev, int log_nonzero = -1) {
     if (log_n < 0 || log_n > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "log_n out of range");
     if (batch == 0) return STARK_OK;
     if (log_n == 0) {   // size-1 transform: identity (n^-1 = 1, g^0 = 1)
@@ -152,10 +152,12 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
         A.log_b = p->log_b[i]; A.log_m = rem; A.stride = 1ull << (rem - A.log_b);
         A.log_c = pick_log_c(A.log_b, rem - A.log_b, log_n);
         A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none; A.pre_direct = (i == 0) ? pre_direct : nullptr; A.tw_direct = p->tw_direct[i];
+        // zero-padded input (LDE): element j is non-zero only for j < 2^log_nonzero; in the first strided pass that is the points p < 2^log_nonzero / stride
+        A.nz_points = (i == 0 && log_nonzero >= 0 && log_nonzero < log_n && (1ull << log_nonzero) >= A.stride) ? (uint32_t)((1ull << log_nonzero) / A.stride) : 0u;
         STARK_TRY(launch_strided<F>(ctx, A, total, src, scratch));
         src = scratch; rem -= A.log_b;
     }
-    A.pre = (p->P == 1) ? pre : none; A.pre_direct = nullptr; A.tw_direct = nullptr;
+    A.pre = (p->P == 1) ? pre : none; A.pre_direct = nullptr; A.tw_direct = nullptr; A.nz_points = 0;
     A.log_b = p->log_b[p->P - 1]; A.stage_tw = p->stage_tw[p->P - 1];
     A.log_b1 = p->P >= 2 ? p->log_b[0] : 0; A.log_b2 = p->P == 3 ? p->log_b[1] : 0;
     A.log_c = p->P == 1 ? 0 : pick_log_c(A.log_b, A.log_b1, log_n);
@@ -169,9 +171,13 @@ static int32_t lde_run(stark_ctx* ctx, const fr_t* evals, int log_n, int log_blo
     const uint64_t n = 1ull << log_n, N = n << log_blowup;
     STARK_HIP(ctx, hipMemcpyAsync(out, evals, n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
     STARK_TRY(ntt_run<F>(ctx, out, log_n, 1, true, nullptr, nullptr));                       // evaluations on H -> coefficients
-    if (N > n) { hipLaunchKernelGGL(k_zero_fill<F>, dim3((unsigned)((N - n + 255) / 256)), dim3(256), 0, ctx->stream, out + n, N - n); STARK_HIP(ctx, hipGetLastError()); }
     fr_t one = fr_one<F>(); bool unit = !coset || fr_eq(*coset, one);
-    return ntt_run<F>(ctx, out, log_n + log_blowup, 1, false, unit ? nullptr : coset, nullptr);   // coefficients -> coset evaluations on the larger domain
+    // The zero padding is never written when the big transform has a strided first pass whose stride divides n: that pass reads
+    // only the n coefficient rows and takes the rest as zero (NttPassArgs::nz_points).  Otherwise (tiny transforms) pad for real.
+    const int big = log_n + log_blowup; int first_b = big <= 10 ? big : (big <= 20 ? (big + 1) / 2 : (big + 2) / 3);
+    const bool skip = N > n && big > 10 && (big - first_b) <= log_n;
+    if (N > n && !skip) { hipLaunchKernelGGL(k_zero_fill<F>, dim3((unsigned)((N - n + 255) / 256)), dim3(256), 0, ctx->stream, out + n, N - n); STARK_HIP(ctx, hipGetLastError()); }
+    return ntt_run<F>(ctx, out, big, 1, false, unit ? nullptr : coset, nullptr, skip ? log_n : -1);   // coefficients -> coset evaluations on the larger domain
 }
 
 void stark::ntt_plans_free(stark_ctx* ctx) { for (auto& kv : ctx->plans) delete kv.second; ctx->plans.clear(); }

@@ -47,6 +47,8 @@ struct NttPassArgs {
     // Direct tables (plans up to 2^24 points): one product per element instead of the two of the two-level lookup.
     const fr_t* tw_direct;   // strided pass: w_m^(rest*k) at index k*stride + rest (the layout of the sub-problem); nullptr => `root` lookup
     const fr_t* pre_direct;  // first pass: g^j at index j; nullptr => `pre` lookup
+    uint32_t nz_points;      // first pass of a zero-padded transform (LDE): only the points p < nz_points of every sub-NTT are non-zero
+                             // in memory; the rest is taken as zero without being read (0 = all points are read)
     uint64_t pre_row_stride; // != 0 (multi-GPU column slabs): the pre-scale exponent of tile element (p, column) is the GLOBAL natural index
                              // p * pre_row_stride + rest0 + column, not the position inside the local slab
 };
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttP
     for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
         const int c = idx & (C - 1), p = idx >> A.log_c;
         const uint64_t g = base + (uint64_t)p * A.stride + c;
+        if (A.nz_points && (uint32_t)p >= A.nz_points) { lds_st(dlo, dhi, idx, fr_zero<F>()); continue; }
         fr_t x = ldg(src + g);
         if (A.pre_direct) x = fr_mul<F>(x, ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1))));
         else if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, A.pre_row_stride ? (uint64_t)p * A.pre_row_stride + A.rest0 + (tile << A.log_c) + c : g));
