@@ -197,6 +197,20 @@ int32_t stark_merkle_verify_many_ds(stark_ctx_t* ctx, size_t cfg_arity, uint64_t
 int32_t stark_merkle_verify_pairs_ds(stark_ctx_t* ctx, size_t cfg_arity, uint64_t tree_label, const uint64_t* root4, const size_t* indices, size_t k, const uint64_t* f_vals, const uint64_t* cp_vals,
                                      const uint8_t* proof, size_t len, int32_t* accepted);
 
+/* ---- sum-check consumer (next row N4) ----------------------------------------------------------------
+ * prove_plain / verify_plain and the Merkle-folded prove_mf / verify_mf (channel/src/lib.rs:1045-1240) over a witness of 2^k field
+ * elements; vk = (k, tree_label[, queries_per_round]) (build_vk_plain / build_vk_mf, :1025-1043).  The witness and every folded
+ * layer are committed with MerkleCommitment (commitment/src/lib.rs:60-114: arity 16, parameters "POSEIDON-T17-X5-SEED") on the GPU;
+ * the Fiat-Shamir channel (:7-117) is a device-resident transcript.  The proof comes back as a stark_proof_t whose bytes are the
+ * bincode 1.x layout of the reference's serde structs ProofPlain / ProofMF (:925-979) — read them with stark_proof_len /
+ * stark_proof_bytes.  verify_*: *accepted = 1 / 0; a failed round check (an assert_eq! panic in the reference) is a rejection. */
+int32_t stark_sumcheck_prove_plain(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, stark_proof_t** out);
+int32_t stark_sumcheck_prove_plain_dev(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, stark_proof_t** out);
+int32_t stark_sumcheck_verify_plain(stark_ctx_t* ctx, size_t k, uint64_t tree_label, const uint8_t* proof, size_t len, int32_t* accepted);
+int32_t stark_sumcheck_prove_mf(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, size_t queries_per_round, stark_proof_t** out);
+int32_t stark_sumcheck_prove_mf_dev(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, size_t queries_per_round, stark_proof_t** out);
+int32_t stark_sumcheck_verify_mf(stark_ctx_t* ctx, size_t k, uint64_t tree_label, size_t queries_per_round, const uint8_t* proof, size_t len, int32_t* accepted);
+
 /* ---- One trace sharded over several GPUs ------------------------------------------
  * The commit phase shards by contiguous blocks (folds, leaf hashes and lower Merkle levels are
  * block-local: stark_fri_fold_dev, stark_leaf_pair_hash_dev, stark_merkle_build_dev with first_pos /

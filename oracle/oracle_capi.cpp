@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include "fri.hpp"
 #include "ntt.hpp"
+#include "channel.hpp"
 
 using namespace oracle;
 
@@ -227,6 +228,57 @@ int oracle_poly_eval_many(int field, const uint64_t* coeffs, size_t n, const uin
 
 // deep_fri_proof_size_bytes recomputed from encoded bytes.
 long oracle_proof_size_estimate_from_bytes(const uint8_t* bytes, size_t n) { DeepFriProof p; if (!decode_proof(bytes, n, p)) return -1; return (long)deep_fri_proof_size_bytes(p); }
+
+// ---- sum-check (N4): prove / verify over the bincode layout of ProofPlain / ProofMF ---------------------------------------
+struct BinDec {
+    const uint8_t* p; size_t n, o = 0; bool bad = false;
+    uint64_t u64() { if (o + 8 > n) { bad = true; return 0; } uint64_t x = 0; for (int j = 0; j < 8; ++j) x |= (uint64_t)p[o + j] << (8 * j); o += 8; return x; }
+    size_t len(size_t item) { uint64_t x = u64(); if (bad || (item && x > (n - o) / item)) { bad = true; return 0; } return (size_t)x; }
+    Fr fbytes() { if (u64() != 32 || o + 32 > n) { bad = true; return Fr::zero(); } uint64_t c[4]; for (int i = 0; i < 4; ++i) { c[i] = 0; for (int j = 0; j < 8; ++j) c[i] |= (uint64_t)p[o + 8 * i + j] << (8 * j); }
+                  o += 32; if (Fr::geq_mod(c)) { bad = true; return Fr::zero(); } return Fr::from_canonical(c); }
+    std::vector<size_t> idxs() { size_t k = len(8); std::vector<size_t> v; for (size_t i = 0; i < k && !bad; ++i) v.push_back((size_t)u64()); return v; }
+    std::vector<Fr> fvec() { size_t k = len(40); std::vector<Fr> v; for (size_t i = 0; i < k && !bad; ++i) v.push_back(fbytes()); return v; }
+    MerkleProof mproof() {
+        MerkleProof m; m.arity = (size_t)u64();
+        size_t g = len(8); for (size_t i = 0; i < g && !bad; ++i) { size_t k = len(1); std::vector<uint8_t> l; for (size_t j = 0; j < k && !bad; ++j) { if (o >= n) { bad = true; break; } l.push_back(p[o++]); } m.group_sizes.push_back(l); }
+        m.indices = idxs();
+        size_t a = len(8); for (size_t i = 0; i < a && !bad; ++i) m.siblings.push_back(fvec());
+        return m;
+    }
+};
+static bool decode_plain(const uint8_t* b, size_t n, ProofPlain& P) {
+    BinDec d{b, n}; P.root = d.fbytes(); size_t k = d.len(80); for (size_t i = 0; i < k && !d.bad; ++i) { Fr c0 = d.fbytes(), c1 = d.fbytes(); P.rounds.push_back({c0, c1}); }
+    if (d.o >= n || b[d.o] != 0) return false; d.o += 1;      // extra_openings: None
+    P.final_eval = d.fbytes(); return !d.bad && d.o == n;
+}
+static bool decode_mf(const uint8_t* b, size_t n, ProofMF& P) {
+    BinDec d{b, n}; P.initial_root = d.fbytes(); size_t k = d.len(120);
+    for (size_t i = 0; i < k && !d.bad; ++i) { RoundMF R; R.c0 = d.fbytes(); R.c1 = d.fbytes(); R.next_root = d.fbytes(); R.cur_indices = d.idxs(); R.cur_values = d.fvec(); R.cur_proof = d.mproof();
+        R.next_indices = d.idxs(); R.next_values = d.fvec(); R.next_proof = d.mproof(); P.rounds.push_back(R); }
+    P.final_eval = d.fbytes(); return !d.bad && d.o == n;
+}
+struct OBytes { std::vector<uint8_t> b; };
+// variant 0: prove_plain, 1: prove_mf(queries_per_round = q)
+int oracle_sumcheck_prove(int variant, size_t k, uint64_t tree_label, size_t q, const uint64_t* witness, void** out) {
+    TRY std::vector<Fr> w = ldv(witness, (size_t)1 << k); OBytes* o = new OBytes();
+    try { o->b = variant == 0 ? encode_proof_plain(prove_plain(k, tree_label, w)) : encode_proof_mf(prove_mf(k, tree_label, q, w)); } catch (...) { delete o; throw; }
+    *out = o; CATCH }
+size_t oracle_bytes_len(void* h) { return ((OBytes*)h)->b.size(); }
+int oracle_bytes_copy(void* h, uint8_t* out) { auto& b = ((OBytes*)h)->b; memcpy(out, b.data(), b.size()); return 0; }
+void oracle_bytes_free(void* h) { delete (OBytes*)h; }
+// 1 accept, 0 reject, -1 undecodable
+int oracle_sumcheck_verify(int variant, size_t k, uint64_t tree_label, size_t q, const uint8_t* bytes, size_t n) {
+    try {
+        if (variant == 0) { ProofPlain P; if (!decode_plain(bytes, n, P)) return -1; return verify_plain(k, tree_label, P) ? 1 : 0; }
+        ProofMF P; if (!decode_mf(bytes, n, P)) return -1; return verify_mf(k, tree_label, q, P) ? 1 : 0;
+    } catch (...) { return 0; }
+}
+// MerkleCommitment::commit root (commitment/src/lib.rs:85-90)
+int oracle_commitment_root(uint64_t tree_label, const uint64_t* leaves, size_t n, uint64_t* root) {
+    TRY MerkleTree t = MerkleTree::make(ldv(leaves, n), commitment_tree_cfg(tree_label)); st(root, t.root); CATCH }
+// Mle::evaluate (channel/src/lib.rs:279-295)
+int oracle_mle_evaluate(const uint64_t* table, size_t k, const uint64_t* r, uint64_t* out) {
+    TRY std::vector<Fr> layer = ldv(table, (size_t)1 << k); for (size_t j = 0; j < k; ++j) layer = fold_layer(layer, ld(r + 4 * j)); st(out, layer[0]); CATCH }
 
 // ---- NTT ---------------------------------------------------------------------------------------
 int oracle_ntt(int field, uint64_t* data, unsigned log_n, int inverse, const uint64_t* coset) {

@@ -173,6 +173,17 @@ struct Transcript {
         state[16] = domain_tag_to_field((const uint8_t*)"FSv1-TRANSCRIPT-INIT", 20);      // :62
         absorb_bytes((const uint8_t*)label, strlen(label));                                // :63
     }
+    Transcript(const uint8_t* label, size_t n, const PoseidonParams& p) : pos(0), params(&p) {   // labels with embedded zero bytes
+        for (int i = 0; i < 17; ++i) state[i] = Fr::zero();
+        state[16] = domain_tag_to_field((const uint8_t*)"FSv1-TRANSCRIPT-INIT", 20);
+        absorb_bytes(label, n);
+    }
+    Fr challenge(const uint8_t* label, size_t n) {                                         // :92-101
+        absorb_field(domain_tag_to_field((const uint8_t*)"FSv1-CHALLENGE", 14));
+        absorb_bytes(label, n);
+        permute(state, *params); pos = 0;
+        return state[0];
+    }
     void absorb_bytes(const uint8_t* b, size_t n) {                                        // :67-73
         absorb_field(domain_tag_to_field((const uint8_t*)"FSv1-ABSORB-BYTES", 17));
         std::vector<Fr> w = bytes_to_field_words(b, n);

@@ -91,6 +91,12 @@ SIGNATURES = {
     "stark_deep_fri_verify": (i32, [vp, vp, sz, vp, sz, sz, u64, C.POINTER(i32)]),
     "stark_merkle_verify_many_ds": (i32, [vp, sz, u64, vp, vp, sz, vp, vp, sz, C.POINTER(i32)]),
     "stark_merkle_verify_pairs_ds": (i32, [vp, sz, u64, vp, vp, sz, vp, vp, vp, sz, C.POINTER(i32)]),
+    "stark_sumcheck_prove_plain": (i32, [vp, vp, sz, u64, vpp]),
+    "stark_sumcheck_prove_plain_dev": (i32, [vp, vp, sz, u64, vpp]),
+    "stark_sumcheck_verify_plain": (i32, [vp, sz, u64, vp, sz, C.POINTER(i32)]),
+    "stark_sumcheck_prove_mf": (i32, [vp, vp, sz, u64, sz, vpp]),
+    "stark_sumcheck_prove_mf_dev": (i32, [vp, vp, sz, u64, sz, vpp]),
+    "stark_sumcheck_verify_mf": (i32, [vp, sz, u64, sz, vp, sz, C.POINTER(i32)]),
     "stark_ali_merge_shard_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, u64, sz, vp, vp]),
     "stark_ali_cstar_from_partials": (i32, [vp, vp, sz, sz, vp]),
     "stark_ali_challenges": (i32, [vp, vp, sz, vp]),

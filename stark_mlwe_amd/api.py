@@ -402,6 +402,33 @@ class Context:
         self._chk(self.lib.stark_merkle_verify_pairs_ds(self.h, cfg.arity, cfg.tree_label, _ptr(_arr(root)), _ptr(ix), len(ix), _ptr(f), _ptr(cp), buf, len(proof), C.byref(ok)))
         return bool(ok.value)
 
+    # ---- sum-check consumer (channel/src/lib.rs:1045-1240) ------------------------------------------------
+    def prove_plain(self, k, tree_label, witness):
+        """prove_plain(&build_vk_plain(k, F::from(tree_label)), witness) -> bincode-layout ProofPlain bytes."""
+        w = _arr(witness); h = C.c_void_p()
+        if w.shape[0] != 1 << k:
+            raise StarkError(-1, "MLE length must be 2^k")
+        self._chk(self.lib.stark_sumcheck_prove_plain(self.h, _ptr(w), k, tree_label, C.byref(h)))
+        return self._proof_out(h)[0]
+
+    def verify_plain(self, k, tree_label, proof: bytes) -> bool:
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0"); ok = C.c_int32(0)
+        self._chk(self.lib.stark_sumcheck_verify_plain(self.h, k, tree_label, buf, len(proof), C.byref(ok)))
+        return bool(ok.value)
+
+    def prove_mf(self, k, tree_label, queries_per_round, witness):
+        """prove_mf(&build_vk_mf(k, F::from(tree_label), q), witness) -> bincode-layout ProofMF bytes."""
+        w = _arr(witness); h = C.c_void_p()
+        if w.shape[0] != 1 << k:
+            raise StarkError(-1, "MLE length must be 2^k")
+        self._chk(self.lib.stark_sumcheck_prove_mf(self.h, _ptr(w), k, tree_label, queries_per_round, C.byref(h)))
+        return self._proof_out(h)[0]
+
+    def verify_mf(self, k, tree_label, queries_per_round, proof: bytes) -> bool:
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0"); ok = C.c_int32(0)
+        self._chk(self.lib.stark_sumcheck_verify_mf(self.h, k, tree_label, queries_per_round, buf, len(proof), C.byref(ok)))
+        return bool(ok.value)
+
     def _proof_out(self, h):
         try:
             ln = self.lib.stark_proof_len(h)

@@ -591,3 +591,5 @@ extern "C" int32_t stark_merkle_open(stark_tree_t* t, const size_t* idx, size_t 
     if (buf) { if (cap < b.size()) return t->ctx->fail(STARK_ERR_INVALID_ARG, "buffer too small"); memcpy(buf, b.data(), b.size()); }
     return STARK_OK;
 }
+
+#include "sumcheck_impl.hpp"

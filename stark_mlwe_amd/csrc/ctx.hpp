@@ -115,6 +115,8 @@ void ntt_plans_free(stark_ctx* ctx);
 int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const fr_t* f_next, size_t n, size_t m, fr_t* h);
 int32_t merkle_build_on(stark_ctx* ctx, hipStream_t st, stark_params* p, size_t arity, uint64_t label, const fr_t* leaves, size_t n, int pairs, const fr_t* cp, size_t cp_div,
                         uint64_t first_pos, uint32_t level0, size_t stop_at_len, bool adopt, stark_tree** out);
+int32_t hash_ds_scattered(stark_ctx* ctx, stark_params* p, int mode, size_t arity, size_t chunk, uint32_t level, uint64_t label, const uint64_t* positions_dev,
+                          const fr_t* in0, const fr_t* in1, size_t n_hashes, fr_t* out);
 int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev);
 int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev);
 int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out);   // one hash, host in/out

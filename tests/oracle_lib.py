@@ -173,6 +173,28 @@ class Oracle:
         buf = (C.c_uint8 * len(proof_bytes)).from_buffer_copy(proof_bytes)
         return self.l.oracle_proof_size_estimate_from_bytes(buf, C.c_size_t(len(proof_bytes)))
 
+    # ---- sum-check (N4) -------------------------------------------------------------------------------
+    def sumcheck_prove(self, variant, k, tree_label, witness, q=2):
+        """variant 0: prove_plain, 1: prove_mf (channel/src/lib.rs:1045, :1130) -> bincode-layout proof bytes."""
+        h = vp(); self.l.oracle_bytes_len.restype = C.c_size_t
+        rc = self.l.oracle_sumcheck_prove(variant, C.c_size_t(k), C.c_uint64(tree_label), C.c_size_t(q), P(A(witness)), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("oracle sumcheck prove failed")
+        n = self.l.oracle_bytes_len(h); buf = (C.c_uint8 * n)(); self.l.oracle_bytes_copy(h, buf); self.l.oracle_bytes_free(h)
+        return bytes(buf)
+
+    def sumcheck_verify(self, variant, k, tree_label, proof: bytes, q=2):
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0")
+        return self.l.oracle_sumcheck_verify(variant, C.c_size_t(k), C.c_uint64(tree_label), C.c_size_t(q), buf, C.c_size_t(len(proof)))
+
+    def commitment_root(self, tree_label, leaves):
+        lv = A(leaves); out = np.zeros(4, np.uint64)
+        assert self.l.oracle_commitment_root(C.c_uint64(tree_label), P(lv), C.c_size_t(lv.shape[0]), P(out)) == 0; return out
+
+    def mle_evaluate(self, table, r):
+        t, rr = A(table), A(r); k = rr.shape[0]; out = np.zeros(4, np.uint64)
+        assert self.l.oracle_mle_evaluate(P(t), C.c_size_t(k), P(rr), P(out)) == 0; return out
+
     # ---- ntt -----------------------------------------------------------------------------------------
     def ntt(self, field, data, inverse=False, coset=None):
         d = A(data).copy(); log_n = int(d.shape[0]).bit_length() - 1

@@ -1,0 +1,49 @@
+"""N4 on the GPU: prove_plain / prove_mf / verify_* through the C-ABI (commits on the Merkle kernels, device-resident transcript)
+against the oracle's restatement of crates/channel/src/lib.rs — byte-identical proofs, the same accept / reject decisions.
+Needs an MI355X: `pytest -m gpu`."""
+import random
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,ds,seed", [(6, 5050, 42), (5, 2025, 7), (1, 1, 1), (12, 2025, 7), (14, 77, 3)])
+def test_prove_plain_bytes_equal_oracle(gpu_ctx, oracle, k, ds, seed):
+    w = oracle.rand_fr_columns(seed, 1 << k, 1)[0]
+    t0 = time.time(); got = gpu_ctx.prove_plain(k, ds, w); dt = time.time() - t0
+    want = oracle.sumcheck_prove(0, k, ds, w)
+    assert got == want
+    assert gpu_ctx.verify_plain(k, ds, got) is True
+    rng = random.Random(k)
+    for pos in [48 + 8 + 5, len(got) - 5] + [rng.randrange(48, len(got)) for _ in range(8)]:
+        bad = bytearray(got); bad[pos] ^= 1 << rng.randrange(8)
+        assert gpu_ctx.verify_plain(k, ds, bytes(bad)) == (oracle.sumcheck_verify(0, k, ds, bytes(bad)) == 1)
+    assert gpu_ctx.verify_plain(k, ds, got[:-1]) is False
+    print(f"prove_plain k={k}: {dt * 1e3:.1f} ms, {len(got)} bytes")
+
+
+@pytest.mark.parametrize("k,ds,q,seed", [(5, 6060, 3, 1337), (6, 11, 2, 5), (3, 9, 8, 2), (1, 4, 1, 3), (12, 2025, 2, 7), (14, 5, 2, 9)])
+def test_prove_mf_bytes_equal_oracle(gpu_ctx, oracle, k, ds, q, seed):
+    """Every folded layer is committed on the GPU (MerkleCommitment: arity 16, "POSEIDON-T17-X5-SEED"): all k+1 roots, the query
+    indices drawn from the device transcript, the openings and the final evaluation must equal the oracle's, byte for byte."""
+    w = oracle.rand_fr_columns(seed, 1 << k, 1)[0]
+    t0 = time.time(); got = gpu_ctx.prove_mf(k, ds, q, w); dt = time.time() - t0
+    want = oracle.sumcheck_prove(1, k, ds, w, q=q)
+    assert got == want
+    assert gpu_ctx.verify_mf(k, ds, q, got) is True
+    rng = random.Random(k * 5 + q)
+    for pos in [8 + 3, len(got) - 5] + [rng.randrange(48, len(got)) for _ in range(10)]:
+        bad = bytearray(got); bad[pos] ^= 1 << rng.randrange(8)
+        assert gpu_ctx.verify_mf(k, ds, q, bytes(bad)) == (oracle.sumcheck_verify(1, k, ds, bytes(bad), q=q) == 1), pos
+    assert gpu_ctx.verify_mf(k, ds + 1, q, got) is False
+    print(f"prove_mf k={k} q={q}: {dt * 1e3:.1f} ms, {len(got)} bytes")
+
+
+def test_sumcheck_argument_errors(gpu_ctx, oracle):
+    from stark_mlwe_amd.api import StarkError
+    w = oracle.rand_fr_columns(1, 48, 1)[0]
+    with pytest.raises(StarkError):
+        gpu_ctx.prove_plain(6, 1, w)            # Mle::new: "MLE length must be 2^k" (:259)
