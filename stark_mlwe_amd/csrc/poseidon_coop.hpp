@@ -163,8 +163,11 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     fr29_t sl = fr29_unpack(s);                                                       // this lane's element; lanes 32..35: accumulators
     fr29_t s0l = bcast29(sl, 0);                                                      // s0, replicated on every lane
     const bool acc_lane = lane >= 32 && lane < 36, sq_lane = lane == 48;
+    { const fr29_t c0 = fr29_unpack(ldg(P.rc_partial)); s0l = add29(s0l, c0); carry29(s0l); }      // x of the very first partial round
     for (int b = 0; b < P.rp / 4; ++b) {
         const size_t r0 = (size_t)(4 * b) * w;
+        fr29_t rc_next0;                                                                  // constant of the NEXT block's first round (none after the last block)
+        { const fr_t c = 4 * b + 4 < P.rp ? ldg(P.rc_partial + 4 * b + 4) : fr_zero<PF>(); rc_next0 = fr29_unpack(c); }
         // this lane's multiplier for each of the four rounds, fetched up front (off the dependent chain)
         fr29_t cst[4], rcq[4];
 #pragma unroll
@@ -184,12 +187,18 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
             for (int d = RATE / 2; d >= 1; d >>= 1) { v = add29(v, shfl_xor29(v, d)); if (++pending == 2) { carry29(v); pending = 0; } }
             if (pending) carry29(v);
             const fr29_t dv = shfl29(v, (lane - 32) << LOG_RATE);                     // lanes 32..35 fetch D_0..D_3 (other lanes: unused)
+            // The round constant of the round that will READ accumulator lane 32+q as its s0 (round q+1 of this block; for q = 3
+            // the first round of the next block) is added here, off the dependent chain: x = s0 + c then needs no add and no
+            // carry pass of its own inside the round.
+            fr29_t rcn;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) sl.l[i] = acc_lane ? dv.l[i] : sl.l[i];
+            for (int i = 0; i < 9; ++i) rcn.l[i] = lane == 32 ? rcq[1].l[i] : (lane == 33 ? rcq[2].l[i] : (lane == 34 ? rcq[3].l[i] : rc_next0.l[i]));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sl.l[i] = acc_lane ? dv.l[i] + rcn.l[i] : sl.l[i];     // limbs < 2^30 until the first round's carry pass
         }
 #define STARK_COOP_ROUND(q)                                                                       \
         {                                                                                         \
-            fr29_t x = add29(s0l, rcq[q]); carry29(x);                                            \
+            const fr29_t x = s0l;                                   /* s0 + c: the constant is already in (block start) */ \
             fr29_t a1;                                                                            \
             _Pragma("unroll") for (int i = 0; i < 9; ++i) a1.l[i] = sq_lane ? x.l[i] : cst[q].l[i]; \
             const fr29_t m1 = fr29_mul_mont<PF>(a1, x);                        /* slot 1 */         \
@@ -253,10 +262,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const fr_t* prefix = J.prefix[b]; const fr_t* suffix = J.suffix[b]; const fr_t* fields = J.fields[b];
     const size_t np = J.np[b], kk = J.k[b], total = np + kk + (size_t)J.ns[b];
     fr_t s = lane == 16 ? J.cap : fr_zero<PF>();
-    for (size_t base = 0; base < total; base += 16) {
-        if (base) s = coop_permute<17>(s, P, L, lane);
+    auto fetch = [&](size_t base) -> fr_t {                                                // this lane's element of the rate block starting at `base`
         const size_t e = base + lane;
-        if (lane < 16 && e < total) s = fr_add<PF>(s, e < np ? ldg(prefix + e) : (e < np + kk ? ldg(fields + (e - np)) : ldg(suffix + (e - np - kk))));
+        if (lane < 16 && e < total) return e < np ? ldg(prefix + e) : (e < np + kk ? ldg(fields + (e - np)) : ldg(suffix + (e - np - kk)));
+        return fr_zero<PF>();
+    };
+    fr_t nxt = fetch(0);
+    for (size_t base = 0; base < total; base += 16) {
+        const fr_t cur = nxt;
+        if (base + 16 < total) nxt = fetch(base + 16);                                    // issued BEFORE the permutation: the HBM latency of the next block hides under it
+        if (base) s = coop_permute<17>(s, P, L, lane);
+        s = fr_add<PF>(s, cur);
     }
     s = coop_permute<17>(s, P, L, lane);
     if (lane == 0) stg(out + b, s);
