@@ -166,18 +166,18 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     { const fr29_t c0 = fr29_unpack(ldg(P.rc_partial)); s0l = add29(s0l, c0); carry29(s0l); }      // x of the very first partial round
     for (int b = 0; b < P.rp / 4; ++b) {
         const size_t r0 = (size_t)(4 * b) * w;
-        fr29_t rc_next0;                                                                  // constant of the NEXT block's first round (none after the last block)
-        { const fr_t c = 4 * b + 4 < P.rp ? ldg(P.rc_partial + 4 * b + 4) : fr_zero<PF>(); rc_next0 = fr29_unpack(c); }
         // this lane's multiplier for each of the four rounds, fetched up front (off the dependent chain)
-        fr29_t cst[4], rcq[4];
+        fr29_t cst[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t* p = nullptr;
             if (lane >= 1 && lane < T) p = c29(P.sparse29, r0 + q * w + T - 1 + lane);                       // w_{q,lane} * 2^20
             else if (acc_lane) { const int qq = lane - 32; if (qq == q) p = c29(P.sparse29, r0 + q * w); else if (qq > q) p = c29(P.gamma29, b * 6 + qq * (qq - 1) / 2 + q); }
             cst[q] = ld29<PF>(p);
-            rcq[q] = fr29_unpack(ldg(P.rc_partial + 4 * b + q));
         }
+        const int rc_idx = 4 * b + (lane - 31);                                       // lane 32 -> round 4b+1, ..., lane 35 -> round 4b+4 (next block's first)
+        const bool rc_ok = acc_lane && rc_idx < P.rp;
+        const fr29_t rcu = fr29_unpack(ldg(P.rc_partial + (rc_ok ? rc_idx : 0)));        // one per-lane load, in flight during the products below
         {   // D_q = sum_j u_{q,j} s_j from the block-start lanes
             const int dq = lane >> LOG_RATE, dj = 1 + (lane & (RATE - 1));
             const fr29_t sj = shfl29(sl, dj);
@@ -192,7 +192,7 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
             // carry pass of its own inside the round.
             fr29_t rcn;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) rcn.l[i] = lane == 32 ? rcq[1].l[i] : (lane == 33 ? rcq[2].l[i] : (lane == 34 ? rcq[3].l[i] : rc_next0.l[i]));
+            for (int i = 0; i < 9; ++i) rcn.l[i] = rc_ok ? rcu.l[i] : 0u;
 #pragma unroll
             for (int i = 0; i < 9; ++i) sl.l[i] = acc_lane ? dv.l[i] + rcn.l[i] : sl.l[i];     // limbs < 2^30 until the first round's carry pass
         }
