@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps and the headline fields (for rocprofv3 kernel stats)")
     ap.add_argument("--e2e-log", type=int, default=20, help="log2 rows of the end-to-end deep_fri_prove section (0 disables)")
+    ap.add_argument("--csv", default=None, help="also write the reference's benchmarkdata.csv schema (end_to_end.rs:42-44) for the reference-input proves")
     args = ap.parse_args()
 
     import numpy as np
@@ -234,6 +235,7 @@ def main():
         if args.e2e_log:
             sections[f"prove_end_to_end_2^{args.e2e_log}"] = dict(prove(args.e2e_log, False), note="build_f0 = the four serial column sponges (fri.rs:548-557), n0/16 dependent permutations each, one wave per column")
         sections["prove_given_f0_2^20"] = dict(prove(20, True), note="deep_fri_prove stages after build_f0 on n0 = 2^20")
+        sections["reference_bench"] = reference_bench(ctx, np, args.csv, world)
 
     if rank == 0:
         traffic = None
@@ -262,6 +264,36 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+PUBLISHED_PROOF_BYTES = {11: 39592, 12: 52000, 13: 60968, 14: 72936, 15: 87736, 16: 101976, 17: 119952, 18: 140032}   # crates/channel/benchmarkdata.csv:2-9
+
+
+def reference_bench(ctx, np, csv_path, gpus):
+    """The reference's own bench (channel/benches/end_to_end.rs:187-374, preset "paper" = [16,16,8], r = 32, seed_z = 0xDEEFBAAD) on its
+    own inputs (seed chain from 1337, one LCG step per k from 11; StdRng + Fp::rand through stark_ref_bench_inputs): prove and verify
+    through the C-ABI; `proof_bytes` is deep_fri_proof_size_bytes and must equal what the reference published."""
+    from stark_mlwe_amd.api import DeepFriParams, ref_bench_inputs
+    prm = DeepFriParams(SCHEDULE, 32, SEED_Z)
+    rows, seed = [], 1337
+    for k in range(11, 17):
+        seed = (seed * 1103515245 + 12345) % 2**64
+        cols = ref_bench_inputs(seed, 1 << k, 4)
+        t0 = time.perf_counter()
+        proof, est, ms = ctx.deep_fri_prove(cols[0], cols[1], cols[2], cols[3], 1 << k, prm)
+        prove_s = time.perf_counter() - t0
+        t0 = time.perf_counter(); ok = ctx.deep_fri_verify(prm, proof); verify_ms = (time.perf_counter() - t0) * 1e3
+        rows.append({"label": "paper", "k": k, "schedule": SCHEDULE, "proof_bytes": est, "published_proof_bytes": PUBLISHED_PROOF_BYTES[k], "matches_published": est == PUBLISHED_PROOF_BYTES[k],
+                     "prove_s": prove_s, "verify_ms": verify_ms, "verified": bool(ok), "prove_elems_per_s": (1 << k) / prove_s, "encoded_bytes": len(proof),
+                     "build_f0_ms": ms[0], "fri_build_ms": ms[1], "queries_encode_ms": ms[2]})
+    if csv_path:
+        with open(csv_path, "w") as f:
+            f.write("csv,label,k,schedule,proof_bytes,prove_s,verify_ms,prove_elems_per_s,delta_size_pct_vs_paper,delta_prove_pct_vs_paper,delta_verify_pct_vs_paper,delta_throughput_pct_vs_paper,gpus,build_f0_ms,fri_build_ms,queries_encode_ms,published_proof_bytes\n")
+            for r in rows:
+                f.write("csv,%s,%d,[%s],%d,%.6f,%.3f,%.6f,0.00,0.00,0.00,0.00,%d,%.3f,%.3f,%.3f,%d\n" % (r["label"], r["k"], ",".join(str(m) for m in r["schedule"]), r["proof_bytes"], r["prove_s"], r["verify_ms"],
+                                                                                                   r["prove_elems_per_s"], gpus, r["build_f0_ms"], r["fri_build_ms"], r["queries_encode_ms"], r["published_proof_bytes"]))
+    return {"rows": rows, "all_match_published": all(r["matches_published"] and r["verified"] for r in rows),
+            "note": "reference published prove 1.85 s / verify 103 ms at k = 11 ... 57.1 s / 212 ms at k = 16 (Apple arm64, 1 thread; benchmarkdata.csv:2-7)"}
 
 
 def _mont_small(x):

@@ -54,6 +54,7 @@ typedef struct stark_tree stark_tree_t;
 typedef struct stark_fri_state stark_fri_state_t;
 typedef struct stark_proof stark_proof_t;
 typedef struct stark_fri_plan stark_fri_plan_t;
+typedef struct stark_transcript stark_transcript_t;
 
 /* ---- context / memory ------------------------------------------------------------------------- */
 int32_t stark_version(void);
@@ -211,6 +212,17 @@ int32_t stark_sumcheck_prove_mf(stark_ctx_t* ctx, const uint64_t* witness, size_
 int32_t stark_sumcheck_prove_mf_dev(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, size_t queries_per_round, stark_proof_t** out);
 int32_t stark_sumcheck_verify_mf(stark_ctx_t* ctx, size_t k, uint64_t tree_label, size_t queries_per_round, const uint8_t* proof, size_t len, int32_t* accepted);
 
+/* ---- Transcript (transcript/src/lib.rs:48-117) -------------------------------------------------------
+ * Transcript::new(label, transcript::default_params()) / absorb_bytes / absorb_field(s) / challenge / challenges as an object:
+ * the 17-lane state and the rate cursor live on the device; absorbs are queued on the host and executed (lazy permute-on-full,
+ * :79-88) by one launch when the next challenge is drawn. */
+int32_t stark_transcript_new(stark_ctx_t* ctx, const uint8_t* label, size_t label_len, stark_transcript_t** out);
+int32_t stark_transcript_absorb_bytes(stark_transcript_t* t, const uint8_t* bytes, size_t n);
+int32_t stark_transcript_absorb_fields(stark_transcript_t* t, const uint64_t* fields, size_t n);
+int32_t stark_transcript_challenge(stark_transcript_t* t, const uint8_t* label, size_t label_len, uint64_t* out4);
+int32_t stark_transcript_challenges(stark_transcript_t* t, const uint8_t* label, size_t label_len, size_t n, uint64_t* out);
+int32_t stark_transcript_free(stark_transcript_t* t);
+
 /* ---- One trace sharded over several GPUs ------------------------------------------
  * The commit phase shards by contiguous blocks (folds, leaf hashes and lower Merkle levels are
  * block-local: stark_fri_fold_dev, stark_leaf_pair_hash_dev, stark_merkle_build_dev with first_pos /
@@ -281,6 +293,10 @@ int32_t stark_comm_all_reduce_u64_dev(stark_ctx_t* ctx, const void* send, void* 
 int32_t stark_comm_gather_dev(stark_ctx_t* ctx, const void* send, void* recv, size_t bytes, int32_t root);
 
 /* ---- synthetic inputs for benchmarks (DESIGN.md "Synthetic inputs") ------------------------------- */
+/* The reference's OWN bench inputs (channel/benches/end_to_end.rs:249-253): ncols vectors of n elements from one
+ * StdRng::seed_from_u64(seed) through ark-ff's Fp::rand, written to HOST memory (host-only, no context): with the seed chain of
+ * end_to_end.rs:214-253 the prover's size estimate must equal the `proof_bytes` the reference published (benchmarkdata.csv). */
+int32_t stark_ref_bench_inputs(uint64_t seed, size_t n, size_t ncols, uint64_t* out);
 int32_t stark_synth_column_dev(stark_ctx_t* ctx, uint64_t seed, uint64_t col, size_t i0, size_t n, uint64_t* out);
 
 #ifdef __cplusplus

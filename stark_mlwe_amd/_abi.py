@@ -123,6 +123,13 @@ SIGNATURES = {
     "stark_comm_all_gather_dev": (i32, [vp, vp, vp, sz]),
     "stark_comm_all_reduce_u64_dev": (i32, [vp, vp, vp, sz]),
     "stark_comm_gather_dev": (i32, [vp, vp, vp, sz, i32]),
+    "stark_transcript_new": (i32, [vp, C.c_char_p, sz, vpp]),
+    "stark_transcript_absorb_bytes": (i32, [vp, C.c_char_p, sz]),
+    "stark_transcript_absorb_fields": (i32, [vp, vp, sz]),
+    "stark_transcript_challenge": (i32, [vp, C.c_char_p, sz, vp]),
+    "stark_transcript_challenges": (i32, [vp, C.c_char_p, sz, sz, vp]),
+    "stark_transcript_free": (i32, [vp]),
+    "stark_ref_bench_inputs": (i32, [u64, sz, sz, vp]),
     "stark_synth_column_dev": (i32, [vp, u64, u64, sz, sz, vp]),
 }
 

@@ -173,6 +173,46 @@ class FriQueryPlan:
             self.h = None
 
 
+class Transcript:
+    """transcript/src/lib.rs:48-117 (device-resident state; absorbs run with the next challenge)."""
+
+    def __init__(self, ctx, label: bytes):
+        self.ctx = ctx; self.h = C.c_void_p()
+        ctx._chk(ctx.lib.stark_transcript_new(ctx.h, label, len(label), C.byref(self.h)))
+
+    def absorb_bytes(self, b: bytes):
+        self.ctx._chk(self.ctx.lib.stark_transcript_absorb_bytes(self.h, b, len(b)))
+
+    def absorb_fields(self, xs):
+        a = _arr(xs).reshape(-1, 4)
+        self.ctx._chk(self.ctx.lib.stark_transcript_absorb_fields(self.h, _ptr(a), a.shape[0]))
+
+    absorb_field = absorb_fields
+
+    def challenge(self, label: bytes):
+        out = np.zeros(4, np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_transcript_challenge(self.h, label, len(label), _ptr(out)))
+        return out
+
+    def challenges(self, label: bytes, n):
+        out = np.zeros((n, 4), np.uint64)
+        self.ctx._chk(self.ctx.lib.stark_transcript_challenges(self.h, label, len(label), n, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.stark_transcript_free(self.h); self.h = None
+
+
+def ref_bench_inputs(seed, n, ncols=4):
+    """The reference's bench inputs (end_to_end.rs:249-253): (ncols, n, 4) uint64 Montgomery limbs.  Host-only."""
+    lib = load_library(); out = np.zeros((ncols * n, 4), np.uint64)
+    rc = lib.stark_ref_bench_inputs(seed, n, ncols, _ptr(out))
+    if rc != 0:
+        raise StarkError(rc, "stark_ref_bench_inputs")
+    return out.reshape(ncols, n, 4)
+
+
 class DeepFriParams:
     """fri.rs:589."""
 

@@ -365,7 +365,67 @@ static int32_t verify_mf_impl(stark_ctx* ctx, uint64_t tree_label, const uint8_t
 
 }  // namespace
 
+// ---- the streaming transcript as an object of the ABI (transcript/src/lib.rs:48-117) ------------------------------------------
+struct stark_transcript { DevTranscript T; explicit stark_transcript(stark_ctx* c) : T(c) {} };
+
 extern "C" {
+
+// Transcript::new(label, default_params()) — the state lives on the device; absorbs are queued and run with the next challenge.
+int32_t stark_transcript_new(stark_ctx_t* ctx, const uint8_t* label, size_t label_len, stark_transcript_t** out) {
+    if (!ctx || !out || (!label && label_len)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    stark_transcript* t = new stark_transcript(ctx);
+    int32_t rc = t->T.init(label, label_len); if (rc) { delete t; return rc; }
+    *out = t; return STARK_OK;
+}
+int32_t stark_transcript_absorb_bytes(stark_transcript_t* t, const uint8_t* bytes, size_t n) { if (!t || (!bytes && n)) return STARK_ERR_INVALID_ARG; t->T.absorb_bytes(bytes, n); return STARK_OK; }
+int32_t stark_transcript_absorb_fields(stark_transcript_t* t, const uint64_t* fields, size_t n) {
+    if (!t || (!fields && n)) return STARK_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n; ++i) t->T.absorb_field(load_fr(fields + 4 * i));
+    return STARK_OK;
+}
+int32_t stark_transcript_challenge(stark_transcript_t* t, const uint8_t* label, size_t label_len, uint64_t* out4) {
+    if (!t || !out4 || (!label && label_len)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(t->T.ctx));
+    fr_t r; STARK_TRY(t->T.challenge(label, label_len, &r)); store_fr(out4, r); return STARK_OK;
+}
+// Transcript::challenges(label, n): challenge(label || le64(i)) for i < n (:103-112)
+int32_t stark_transcript_challenges(stark_transcript_t* t, const uint8_t* label, size_t label_len, size_t n, uint64_t* out) {
+    if (!t || (!out && n) || (!label && label_len)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(t->T.ctx));
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<uint8_t> tag(label, label + label_len); for (int j = 0; j < 8; ++j) tag.push_back((uint8_t)((uint64_t)i >> (8 * j)));
+        fr_t r; STARK_TRY(t->T.challenge(tag.data(), tag.size(), &r)); store_fr(out + 4 * i, r);
+    }
+    return STARK_OK;
+}
+int32_t stark_transcript_free(stark_transcript_t* t) { if (!t) return STARK_ERR_INVALID_ARG; delete t; return STARK_OK; }
+
+// The reference's bench inputs (channel/benches/end_to_end.rs:249-253): `ncols` vectors of n elements drawn one after the other
+// from ONE StdRng::seed_from_u64(seed) with ark-ff's Fp::rand (rand_core 0.6.4 PCG32 seed expansion, ChaCha12, rejection sampling of
+// 255-bit candidates; the accepted limbs ARE the Montgomery representation).  Host-only: no context, no device.
+int32_t stark_ref_bench_inputs(uint64_t seed, size_t n, size_t ncols, uint64_t* out) {
+    if (!out && n * ncols) return STARK_ERR_INVALID_ARG;
+    uint8_t key[32]; uint64_t state = seed;
+    for (int c = 0; c < 8; ++c) {                                                          // SeedableRng::seed_from_u64
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+        const uint32_t x = (xs >> rot) | (xs << ((32 - rot) & 31));
+        key[4 * c] = (uint8_t)x; key[4 * c + 1] = (uint8_t)(x >> 8); key[4 * c + 2] = (uint8_t)(x >> 16); key[4 * c + 3] = (uint8_t)(x >> 24);
+    }
+    host::ChaCha12Rng rng(key);
+    for (size_t i = 0; i < n * ncols; ++i) {
+        for (;;) {                                                                         // Fp::rand: 4 limbs, top bit cleared, accept below the modulus
+            uint64_t l[4]; for (int j = 0; j < 4; ++j) l[j] = rng.next_u64();
+            l[3] &= 0x7FFFFFFFFFFFFFFFull;
+            uint32_t t[9]; for (int j = 0; j < 4; ++j) { t[2 * j] = (uint32_t)l[j]; t[2 * j + 1] = (uint32_t)(l[j] >> 32); } t[8] = 0;
+            if (fr_geq_p<PallasFr>(t)) continue;
+            for (int j = 0; j < 4; ++j) out[4 * i + j] = l[j];
+            break;
+        }
+    }
+    return STARK_OK;
+}
 
 int32_t stark_sumcheck_prove_plain_dev(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, stark_proof_t** out) {
     if (!ctx || !witness || !out) return STARK_ERR_INVALID_ARG;

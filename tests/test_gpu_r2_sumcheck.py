@@ -47,3 +47,22 @@ def test_sumcheck_argument_errors(gpu_ctx, oracle):
     w = oracle.rand_fr_columns(1, 48, 1)[0]
     with pytest.raises(StarkError):
         gpu_ctx.prove_plain(6, 1, w)            # Mle::new: "MLE length must be 2^k" (:259)
+
+
+def test_transcript_object_matches_reference_flow(gpu_ctx, oracle):
+    """transcript/src/lib.rs:119-152 shapes: new(label); absorb_bytes(msg); challenge(label) is deterministic and equals the oracle's
+    transcript; a second challenge, long byte strings (several 31-byte words, several permutations) and `challenges` (label || le64(i))."""
+    from stark_mlwe_amd.api import Transcript
+    for label, msg, ch in ((b"test", b"hello", b"alpha"), (b"FSv1", b"x" * 100, b"c"), (b"L", b"", b"z")):
+        t = Transcript(gpu_ctx, label); t.absorb_bytes(msg); got = t.challenge(ch); t.free()
+        assert (got == oracle.transcript_vec(label, msg, ch)).all()
+        t2 = Transcript(gpu_ctx, label); t2.absorb_bytes(msg); assert (t2.challenge(ch) == got).all(); t2.free()      # determinism (:124-136)
+    # absorb_fields over several rate blocks + two challenges = tr_hash_fields_tagged's framing built by hand (fri.rs:28-35)
+    xs = oracle.synth_column(9, 9, 0, 40)
+    t = Transcript(gpu_ctx, b"FRI/FS"); t.absorb_bytes(b"ALI/A"); t.absorb_fields(xs)
+    assert (t.challenge(b"out") == oracle.tr_hash_fields_tagged(b"ALI/A", xs)).all()
+    c2 = t.challenge(b"out"); assert not (c2 == oracle.tr_hash_fields_tagged(b"ALI/A", xs)).all()                        # the state moved on
+    t.free()
+    t = Transcript(gpu_ctx, b"chs"); many = t.challenges(b"r", 3); t.free()
+    t = Transcript(gpu_ctx, b"chs"); one = [t.challenge(b"r" + i.to_bytes(8, "little")) for i in range(3)]; t.free()
+    assert all((many[i] == one[i]).all() for i in range(3))                                                          # :103-112
