@@ -32,6 +32,7 @@ SIGNATURES = {
     "stark_ctx_sync": (i32, [vp]),
     "stark_ctx_trim": (i32, [vp]),
     "stark_ctx_cached_bytes": (sz, [vp]),
+    "stark_ctx_set_option": (i32, [vp, C.c_char_p, C.c_int64]),
     "stark_last_error": (C.c_char_p, [vp]),
     "stark_malloc": (i32, [vp, sz, vpp]),
     "stark_free": (i32, [vp, vp]),

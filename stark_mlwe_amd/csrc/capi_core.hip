@@ -16,8 +16,8 @@ using namespace stark;
 static const size_t kMaxLds = 160 * 1024;
 static inline int poseidon_block(int t) { return (size_t)t * 32 * 64 <= kMaxLds ? 64 : 32; }
 static inline size_t poseidon_lds(int t, int block) { return (size_t)t * 32 * block; }
-// the wave-pair kernels (poseidon_pair.hpp) serve the hot widths; STARK_POSEIDON_IMPL=lane selects the one-lane-per-sponge form
-static inline bool use_pair(int t) { static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }(); return !lane_only && (t == 9 || t == 17); }
+// the wave-pair kernels (poseidon_pair.hpp) serve the hot widths; the "poseidon_lane_only" option selects the one-lane-per-sponge form (diagnostic)
+static inline bool use_pair(const stark_ctx* ctx, int t) { return !ctx->opt_poseidon_lane_only && (t == 9 || t == 17); }
 
 namespace stark {
 
@@ -145,8 +145,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tag, "out", &frame, &np, &ns));
     if (n == 0) return STARK_OK;
     TrJob J; J.prefix = frame; J.np = np; J.suffix = frame + np; J.ns = ns; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.k = k; J.n = n;
-    static const bool lane_only = [] { const char* e = getenv("STARK_POSEIDON_IMPL"); return e && std::string(e) == "lane"; }();
-    if (!lane_only && n <= 4096) {
+    if (!ctx->opt_poseidon_lane_only && n <= 4096) {
         // few (or one, possibly very long) sponges: one wave per sponge, latency-oriented (poseidon_coop.hpp)
         hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(17), st, tp->dev, J, fields_dev, out_dev);
         STARK_HIP(ctx, hipGetLastError());
@@ -261,9 +260,25 @@ int32_t stark_ctx_trim(stark_ctx_t* ctx) {
     if (!ctx) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx));
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& kv : ctx->pool_free) { for (void* q : kv.second) (void)hipFree(q); kv.second.clear(); }
-    ctx->pool_cached_bytes = 0; return STARK_OK;
+    ctx->pool_cached_bytes = 0;
+    stark::ntt_plans_free(ctx);                  // NTT plans with their direct twiddle / coset tables (up to 3*n*32 B per plan) are rebuilt on demand
+    if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    return STARK_OK;
 }
 size_t stark_ctx_cached_bytes(stark_ctx_t* ctx) { return ctx ? ctx->pool_cached_bytes : 0; }
+int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const std::string k(key);
+    if (k == "ntt_direct_max_log") { if (value < 0 || value > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_direct_max_log: 0..30"); ctx->opt_ntt_direct_max_log = (int)value; }
+    else if (k == "ntt_log_tile") { if (value != -1 && (value < 8 || value > 12)) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_log_tile: 8..12, or -1 for the default"); ctx->opt_ntt_log_tile_forced = value != -1; ctx->opt_ntt_log_tile = value == -1 ? 11 : (int)value; }
+    else if (k == "ntt_min_waves") { if (value != 2 && value != 4) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_min_waves: 2 or 4"); ctx->opt_ntt_min_waves = (int)value; }
+    else if (k == "poseidon_lane_only") ctx->opt_poseidon_lane_only = value != 0;
+    else return ctx->fail(STARK_ERR_INVALID_ARG, "unknown option '" + k + "' (ntt_direct_max_log, ntt_log_tile, ntt_min_waves, poseidon_lane_only)");
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    stark::ntt_plans_free(ctx);                  // plans (and their direct tables) are rebuilt lazily under the new options
+    return STARK_OK;
+}
 const char* stark_last_error(stark_ctx_t* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int32_t stark_malloc(stark_ctx_t* ctx, size_t bytes, void** dptr) { if (!ctx || !dptr) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx)); STARK_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 32)); return STARK_OK; }
 int32_t stark_free(stark_ctx_t* ctx, void* dptr) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); STARK_HIP(ctx, hipFree(dptr)); return STARK_OK; }
@@ -388,13 +403,13 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* 
     if (chunk) J.arity = chunk;          // the verifier's groups: DS field `arity` as given, `chunk` children per hash (a short last chunk of the proof's level)
     J.n_out = mode == 1 ? n_in : (n_in + J.arity - 1) / J.arity;
     if (!J.n_out) return STARK_OK;
-    if (use_pair(p->dev.t) && J.n_out <= 8192) {
+    if (use_pair(ctx, p->dev.t) && J.n_out <= 8192) {
         // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
         if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), st, p->dev, J, in0, in1, out);
         else hipLaunchKernelGGL(k_hash_ds_coop<9>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(9), st, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
-    if (use_pair(p->dev.t)) {
+    if (use_pair(ctx, p->dev.t)) {
         if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds2<17>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(17), st, p->dev, J, in0, in1, out);
         else hipLaunchKernelGGL(k_hash_ds2<9>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(9), st, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
@@ -441,7 +456,7 @@ int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const f
     if (!n) return STARK_OK;
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
     fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
-    if (use_pair(17)) {
+    if (use_pair(ctx, 17)) {
         hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), st, tp->dev, init + 17, f, f_next, n, m, h);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }

@@ -36,9 +36,9 @@ struct NttPlan {
 }  // namespace stark
 
 static const size_t kMaxLds = 160 * 1024;
-// direct (one-product) twiddle / coset tables for transforms up to 2^STARK_NTT_DIRECT points (default 24; 0 disables): they cost
+// direct (one-product) twiddle / coset tables for transforms up to 2^ntt_direct_max_log points (option, default 24; 0 disables): they cost
 // n*32 B of HBM per strided pass and plan, which the VALU-bound transform does not notice, and save a product per element and pass
-static inline int ntt_direct_max() { static const int v = [] { const char* e = getenv("STARK_NTT_DIRECT"); return e ? atoi(e) : 24; }(); return v; }
+static inline int ntt_direct_max(const stark_ctx* ctx) { return ctx->opt_ntt_direct_max_log; }
 
 template <class F>
 static int32_t fill_table(stark_ctx* ctx, const fr_t& g, const fr_t& c0, int lo_bits, int hi_bits, DevTable& T) {
@@ -68,7 +68,7 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
         DevTable T; int32_t rc = fill_table<F>(ctx, wb, fr_one<F>(), lb > 0 ? lb - 1 : 0, 0, T); if (rc) return bail(rc);
         p->stage_tw[i] = T.lo; (void)hipFree(T.hi);
     }
-    if (ntt_direct_max() >= log_n) {       // direct twiddle tables: 2^log_m entries per strided pass
+    if (ntt_direct_max(ctx) >= log_n) {       // direct twiddle tables: 2^log_m entries per strided pass
         int rem = log_n;
         for (int i = 0; i + 1 < p->P; ++i) {
             if (hipMalloc((void**)&p->tw_direct[i], ((size_t)1 << rem) * sizeof(fr_t)) != hipSuccess) { p->tw_direct[i] = nullptr; (void)hipGetLastError(); break; }   // no memory: keep the two-level lookup
@@ -88,12 +88,11 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
 static inline size_t ntt_lds_bytes(int log_b, int log_c) { return (((size_t)2 << (log_b + log_c)) + ((size_t)1 << log_b)) * 16; }
 // one workgroup per CU (tile > 80 KiB of LDS) => 512 threads so that every SIMD still holds 2 waves
 static inline unsigned ntt_threads(size_t lds) { return lds > 80 * 1024 ? 512u : 256u; }
-// tile elements E = B*C: 2^11 by default (64 KiB + twiddles => 2 workgroups per CU); STARK_NTT_LOG_E overrides for tuning
-static inline int ntt_log_e() { static const int v = [] { const char* e = getenv("STARK_NTT_LOG_E"); int x = e ? atoi(e) : 11; return x < 8 ? 8 : (x > 12 ? 12 : x); }(); return v; }
-static inline int ntt_minw() { static const int v = [] { const char* e = getenv("STARK_NTT_MINW"); return e ? atoi(e) : 2; }(); return v; }
+// tile elements E = B*C: 2^11 by default (64 KiB + twiddles => 2 workgroups per CU); option "ntt_log_tile" overrides for tuning
+static inline int ntt_minw(const stark_ctx* ctx) { return ctx->opt_ntt_min_waves; }
 // total_log: log2 of all elements the launch covers; small launches take smaller tiles so that the grid still fills the chip
-static inline int pick_log_c(int log_b, int cap, int total_log = 30) {
-    int le = ntt_log_e(); if (!getenv("STARK_NTT_LOG_E") && total_log - le < 9) le = std::max(8, std::min(le, total_log - 8));
+static inline int pick_log_c(const stark_ctx* ctx, int log_b, int cap, int total_log = 30) {
+    int le = ctx->opt_ntt_log_tile; if (!ctx->opt_ntt_log_tile_forced && total_log - le < 9) le = std::max(8, std::min(le, total_log - 8));
     int lc = std::max(2, le - log_b); return std::max(0, std::min(lc, cap));
 }
 
@@ -102,7 +101,7 @@ static int32_t launch_strided(stark_ctx* ctx, NttPassArgs A, uint64_t total_elem
     size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
     if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
     uint64_t tiles = total_elems >> (A.log_b + A.log_c);
-    if (ntt_minw() > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_strided<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    if (ntt_minw(ctx) > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_strided<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
     else hipLaunchKernelGGL((k_ntt_strided<F, 2>), dim3((unsigned)tiles), dim3(ntt_threads(lds)), lds, ctx->stream, A, src, dst);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
@@ -111,7 +110,7 @@ static int32_t launch_last(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, 
     size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
     if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
     uint64_t tiles = total_elems >> (A.log_b + A.log_c);
-    if (ntt_minw() > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_last<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
+    if (ntt_minw(ctx) > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_last<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
     else hipLaunchKernelGGL((k_ntt_last<F, 2>), dim3((unsigned)tiles), dim3(ntt_threads(lds)), lds, ctx->stream, A, src, dst);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
@@ -134,7 +133,7 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
             else STARK_TRY(fill_table<F>(ctx, fr_inv<F>(*coset), fr_inv<F>(fr_from_u64<F>(1ull << log_n)), lo_bits, hi_bits, p->coset_tab));   // n^-1 g^-k
             p->coset = *coset; p->have_coset = true;
             if (p->coset_direct) { (void)hipFree(p->coset_direct); p->coset_direct = nullptr; }
-            if (!inverse && ntt_direct_max() >= log_n && hipMalloc((void**)&p->coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess)
+            if (!inverse && ntt_direct_max(ctx) >= log_n && hipMalloc((void**)&p->coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess)
                 hipLaunchKernelGGL(k_fill_pow_direct<F>, dim3((unsigned)((((uint64_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, p->coset_tab.view(), 1ull << log_n, p->coset_direct);
             else (void)hipGetLastError();
         }
@@ -150,7 +149,7 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     int rem = log_n;                       // log2 of the current sub-problem size
     for (int i = 0; i + 1 < p->P; ++i) {   // strided passes
         A.log_b = p->log_b[i]; A.log_m = rem; A.stride = 1ull << (rem - A.log_b);
-        A.log_c = pick_log_c(A.log_b, rem - A.log_b, log_n);
+        A.log_c = pick_log_c(ctx, A.log_b, rem - A.log_b, log_n);
         A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none; A.pre_direct = (i == 0) ? pre_direct : nullptr; A.tw_direct = p->tw_direct[i];
         // zero-padded input (LDE): element j is non-zero only for j < 2^log_nonzero; in the first strided pass that is the points p < 2^log_nonzero / stride
         A.nz_points = (i == 0 && log_nonzero >= 0 && log_nonzero < log_n && (1ull << log_nonzero) >= A.stride) ? (uint32_t)((1ull << log_nonzero) / A.stride) : 0u;
@@ -160,7 +159,7 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     A.pre = (p->P == 1) ? pre : none; A.pre_direct = nullptr; A.tw_direct = nullptr; A.nz_points = 0;
     A.log_b = p->log_b[p->P - 1]; A.stage_tw = p->stage_tw[p->P - 1];
     A.log_b1 = p->P >= 2 ? p->log_b[0] : 0; A.log_b2 = p->P == 3 ? p->log_b[1] : 0;
-    A.log_c = p->P == 1 ? 0 : pick_log_c(A.log_b, A.log_b1, log_n);
+    A.log_c = p->P == 1 ? 0 : pick_log_c(ctx, A.log_b, A.log_b1, log_n);
     A.post = post; A.scale = post.lo ? nullptr : (scale_override_dev ? scale_override_dev : (inverse ? p->scale : nullptr));
     STARK_TRY(launch_last<F>(ctx, A, total, src, data));
     return STARK_OK;
@@ -201,7 +200,7 @@ static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t nc
     NttPlan* sm = nullptr; STARK_TRY(get_plan<F>(ctx, log_rows, inverse, &sm));       // stage twiddles of w_R (P == 1 plan)
     NttPassArgs A; memset(&A, 0, sizeof(A));
     int log_cols = 0; while ((1ull << log_cols) < ncols) ++log_cols;
-    A.log_b = log_rows; A.log_c = pick_log_c(log_rows, log_cols); A.log_n = log_n; A.stride = ncols; A.log_m = log_n;
+    A.log_b = log_rows; A.log_c = pick_log_c(ctx, log_rows, log_cols); A.log_n = log_n; A.stride = ncols; A.log_m = log_n;
     A.stage_tw = sm->stage_tw[0]; A.root = big->root.view(); A.rest0 = col0;
     if (shift && !fr_eq(*shift, fr_one<F>())) {
         // coset evaluation: x[j] *= shift^j with j the GLOBAL natural index of the element (row * C + global column)

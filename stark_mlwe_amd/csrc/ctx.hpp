@@ -60,6 +60,13 @@ struct stark_ctx {
     std::vector<OmegaTab> omega_tabs;                                  // two-level power tables of a domain generator (DomainH, deep_ali/src/lib.rs:109-125)
     void* pinned = nullptr; size_t pinned_bytes = 0;                   // small pinned staging area for async uploads / downloads
 
+    // tuning / diagnostic options (stark_ctx_set_option): explicit API state, never the environment
+    int opt_ntt_direct_max_log = 24;     // direct (one-product) twiddle / coset tables for transforms up to 2^this (0 disables)
+    int opt_ntt_log_tile = 11;           // log2 of the elements of an NTT tile (8..12); -1 would mean "auto" (the default also shrinks for small launches)
+    bool opt_ntt_log_tile_forced = false;
+    int opt_ntt_min_waves = 2;           // occupancy hint of the NTT kernels (2 or 4 waves per SIMD)
+    bool opt_poseidon_lane_only = false; // one-lane-per-sponge kernels instead of the wave-pair / one-wave forms (diagnostic)
+
     int32_t fail(int32_t code, const std::string& msg) { err = msg; return code; }
 };
 

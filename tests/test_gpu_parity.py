@@ -526,22 +526,27 @@ def test_full_size_proof_accepted_by_reference_verifier(gpu_ctx, oracle, log_n0,
 
 def test_ntt_two_level_twiddle_path_matches_direct_tables(gpu_ctx, oracle):
     """Transforms above 2^24 points (BASELINE's 2^26 config) take the two-level power-table lookup instead of the direct
-    twiddle / coset tables.  The same code path is forced at 2^21 in a child process (STARK_NTT_DIRECT=0, read once per
-    process) and must give the bytes of the direct-table path, for the plain and the coset transform, forward and inverse."""
-    import hashlib, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, hashlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
-        "import oracle_lib; from stark_mlwe_amd.api import Context, PALLAS_FR\n"
-        "o = oracle_lib.Oracle(); c = Context(0); x = o.synth_column(21, 7, 0, 1 << 21); g = o.from_u64(5)\n"
-        "y = c.fft(x, field=PALLAS_FR); z = c.fft(x, field=PALLAS_FR, coset=g); w = c.ifft(z, field=PALLAS_FR, coset=g)\n"
-        "print(hashlib.sha256(y.tobytes() + z.tobytes()).hexdigest(), bool((w == x).all())); c.close()\n" % (root, root))
-    env = dict(os.environ, STARK_NTT_DIRECT="0")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-800:]
-    digest, roundtrip = out.stdout.split()[-2:]
+    twiddle / coset tables.  The same code path is forced at 2^21 on a second context (`stark_ctx_set_option
+    "ntt_direct_max_log" = 0` — an explicit option, nothing is read from the environment) and must give the bytes of the
+    direct-table path, for the plain and the coset transform, forward and inverse; other tile sizes / occupancies too."""
+    from stark_mlwe_amd.api import Context, StarkError
     x = oracle.synth_column(21, 7, 0, 1 << 21); g = oracle.from_u64(5)
     y = gpu_ctx.fft(x, field=PALLAS_FR); z = gpu_ctx.fft(x, field=PALLAS_FR, coset=g)
-    assert roundtrip == "True"
-    assert digest == hashlib.sha256(y.tobytes() + z.tobytes()).hexdigest()
+    c = Context(0)
+    try:
+        c.set_option("ntt_direct_max_log", 0)
+        assert (c.fft(x, field=PALLAS_FR) == y).all() and (c.fft(x, field=PALLAS_FR, coset=g) == z).all()
+        assert (c.ifft(z, field=PALLAS_FR, coset=g) == x).all()
+        for key, val in (("ntt_log_tile", 9), ("ntt_log_tile", 12), ("ntt_min_waves", 4), ("ntt_log_tile", -1)):
+            c.set_option(key, val)
+            assert (c.fft(x, field=PALLAS_FR, coset=g) == z).all(), (key, val)
+        c.set_option("poseidon_lane_only", 1)
+        f = oracle.synth_column(2, 1, 0, 200)
+        assert (c.leaf_pair_hash(f, None, 1) == oracle.leaf_pair_hash(f, None, 1)).all()
+        with pytest.raises(StarkError):
+            c.set_option("no_such_option", 1)
+        with pytest.raises(StarkError):
+            c.set_option("ntt_log_tile", 5)
+    finally:
+        c.close()
     assert (gpu_ctx.ifft(z, field=PALLAS_FR, coset=g) == x).all()
