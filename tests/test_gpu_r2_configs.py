@@ -226,11 +226,12 @@ def test_library_rccl_communicator_one_rank(gpu_ctx):
     assert gpu_ctx.lib.stark_comm_all_to_all_dev(gpu_ctx.h, C.c_void_p(y.data_ptr()), C.c_void_p(z2.data_ptr()), 128) == -3      # STARK_ERR_RCCL
 
 
-@pytest.mark.parametrize("log_n", [12, 16])
+@pytest.mark.parametrize("log_n", [12, 16, 22])
 def test_sharded_trace_world1_equals_single_gpu_step(gpu_ctx, oracle, log_n):
     """The N > 1 bench step (ShardedLde = 2^b coset transforms through the six-step building blocks + pack kernels, shard merge,
     sharded commit) on ONE rank through the library's communicator must give the roots of the single-GPU step (stark_lde_dev,
-    stark_ali_merge_dev, stark_fri_build_dev) — and, at 2^12, the oracle's."""
+    stark_ali_merge_dev, stark_fri_build_dev) — and, at 2^12, the oracle's.  2^22 rows (LDE to 2^25, six-step transforms of
+    2^22 points) is the largest trace whose two code paths fit a test's time budget side by side."""
     import torch
     import bench
     from stark_mlwe_amd import dist as sd
