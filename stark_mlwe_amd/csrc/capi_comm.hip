@@ -13,6 +13,7 @@
 // communicator is asked for; when torch is in the process its bundled RCCL is reused.
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include "ctx.hpp"
 
 using namespace stark;
@@ -35,7 +36,9 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    std::mutex mu;
     bool load() {
+        std::lock_guard<std::mutex> lock(mu);          // contexts on different host threads may ask at the same time
         if (tried) return h != nullptr;
         tried = true;
         const char* names[] = {"librccl.so", "librccl.so.1"};
