@@ -7,6 +7,8 @@
 //! crates/merkle/src/lib.rs     MerkleTree::new / new_pairs / open_many, verify_many_ds / verify_pairs_ds -> merkle::*
 //! crates/deep_ali/src/fri.rs   fri_fold_layer, compute_s_layer, fri_build_transcript, build_f0, deep_fri_prove, deep_fri_verify -> fri::*
 //! crates/fft/src/lib.rs        fft, ifft, fft_in_place, ifft_in_place                            -> fft::*
+//! crates/transcript/src/lib.rs Transcript::{new, absorb_bytes, absorb_fields, challenge, challenges} -> transcript::*
+//! crates/channel/src/lib.rs    prove_plain, verify_plain, prove_mf, verify_mf                     -> channel::*
 //! ```
 //! Field elements cross the boundary as they sit in memory: `ark_ff::Fp<MontBackend<_,4>,4>` is `Fp(BigInt<4>([u64;4]),
 //! PhantomData)` — 4 little-endian limbs in Montgomery form — so `&[F]` is handed over as `*const u64` without copying.
@@ -313,6 +315,76 @@ pub mod fft {
         let c = coset.as_ref().map(limb1).unwrap_or(ptr::null());
         ctx.chk(unsafe { stark_lde(ctx.raw, STARK_FIELD_PALLAS_FR, limbs(evals), evals.len().trailing_zeros() as usize, log_blowup, c, limbs_mut(&mut out)) });
         out
+    }
+}
+
+pub mod transcript {
+    //! `Transcript` (transcript/src/lib.rs:48-117) with the state on the device: absorbs are queued and executed by one launch
+    //! when the next challenge is drawn.  Parameters are `transcript::default_params()`.
+    use super::*;
+    pub struct Transcript { raw: *mut stark_transcript_t }
+    impl Transcript {
+        /// `Transcript::new(label, default_params())` — :55-65.
+        pub fn new(ctx: &Ctx, label: &[u8]) -> Self {
+            let mut raw = ptr::null_mut();
+            ctx.chk(unsafe { stark_transcript_new(ctx.raw(), label.as_ptr(), label.len(), &mut raw) });
+            Transcript { raw }
+        }
+        /// `absorb_bytes` — :67-73.
+        pub fn absorb_bytes(&mut self, ctx: &Ctx, bytes: &[u8]) { ctx.chk(unsafe { stark_transcript_absorb_bytes(self.raw, bytes.as_ptr(), bytes.len()) }); }
+        /// `absorb_field` / `absorb_fields` — :75-88.
+        pub fn absorb_fields(&mut self, ctx: &Ctx, xs: &[F]) { ctx.chk(unsafe { stark_transcript_absorb_fields(self.raw, limbs(xs), xs.len()) }); }
+        /// `challenge(label)` — :92-101.
+        pub fn challenge(&mut self, ctx: &Ctx, label: &[u8]) -> F {
+            let mut r = F::from(0u64);
+            ctx.chk(unsafe { stark_transcript_challenge(self.raw, label.as_ptr(), label.len(), &mut r as *mut F as *mut u64) });
+            r
+        }
+        /// `challenges(label, n)` — :103-112.
+        pub fn challenges(&mut self, ctx: &Ctx, label: &[u8], n: usize) -> Vec<F> {
+            let mut out = vec![F::from(0u64); n];
+            ctx.chk(unsafe { stark_transcript_challenges(self.raw, label.as_ptr(), label.len(), n, limbs_mut(&mut out)) });
+            out
+        }
+    }
+    impl Drop for Transcript { fn drop(&mut self) { unsafe { stark_transcript_free(self.raw); } } }
+}
+
+pub mod channel {
+    //! crates/channel/src/lib.rs:1045-1240 — the NIZK entry points of the sum-check consumer.  The returned bytes are the bincode 1.x
+    //! layout of `ProofPlain` / `ProofMF`, so `bincode::deserialize::<ProofPlain>(&bytes)` yields the reference's struct.
+    use super::*;
+    fn take(ctx: &Ctx, raw: *mut stark_proof_t) -> Vec<u8> {
+        let mut bytes = vec![0u8; unsafe { stark_proof_len(raw) }];
+        ctx.chk(unsafe { stark_proof_bytes(raw, bytes.as_mut_ptr()) });
+        unsafe { stark_proof_free(raw); }
+        bytes
+    }
+    /// `prove_plain(vk, witness)` — :1045-1076 (vk = build_vk_plain(k, F::from(tree_label))).
+    pub fn prove_plain(ctx: &Ctx, k: usize, tree_label: u64, witness: &[F]) -> Vec<u8> {
+        assert!(witness.len() == 1 << k, "MLE length must be 2^k");                        // :259
+        let mut raw = ptr::null_mut();
+        ctx.chk(unsafe { stark_sumcheck_prove_plain(ctx.raw(), limbs(witness), k, tree_label, &mut raw) });
+        take(ctx, raw)
+    }
+    /// `verify_plain(vk, proof)` — :1080-1128.
+    pub fn verify_plain(ctx: &Ctx, k: usize, tree_label: u64, proof: &[u8]) -> bool {
+        let mut ok = 0i32;
+        ctx.chk(unsafe { stark_sumcheck_verify_plain(ctx.raw(), k, tree_label, proof.as_ptr(), proof.len(), &mut ok) });
+        ok == 1
+    }
+    /// `prove_mf(vk, witness)` — :1130-1172 (vk = build_vk_mf(k, F::from(tree_label), queries_per_round)).
+    pub fn prove_mf(ctx: &Ctx, k: usize, tree_label: u64, queries_per_round: usize, witness: &[F]) -> Vec<u8> {
+        assert!(witness.len() == 1 << k, "MLE length must be 2^k");
+        let mut raw = ptr::null_mut();
+        ctx.chk(unsafe { stark_sumcheck_prove_mf(ctx.raw(), limbs(witness), k, tree_label, queries_per_round, &mut raw) });
+        take(ctx, raw)
+    }
+    /// `verify_mf(vk, proof)` — :1176-1240.
+    pub fn verify_mf(ctx: &Ctx, k: usize, tree_label: u64, queries_per_round: usize, proof: &[u8]) -> bool {
+        let mut ok = 0i32;
+        ctx.chk(unsafe { stark_sumcheck_verify_mf(ctx.raw(), k, tree_label, queries_per_round, proof.as_ptr(), proof.len(), &mut ok) });
+        ok == 1
     }
 }
 
