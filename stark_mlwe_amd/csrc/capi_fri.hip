@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <map>
 #include "ctx.hpp"
 #include "fri_dev.hpp"
 
@@ -252,12 +253,57 @@ static int32_t shape_of_state(stark_ctx* ctx, stark_fri_state* S, size_t n0, Fri
     if (!sh.make(n0, S->schedule.data(), S->schedule.size(), S->roots.data(), err)) return ctx->fail(STARK_ERR_INVALID_ARG, err);
     return STARK_OK;
 }
-// fri_prove_queries + payload assembly + canonical encoding (fri.rs:355-466, 613-640): fri_plan.hpp over the local state.
+// Transcript hashes of the query phase are pure functions of their inputs: the plan pass and the assembling pass ask for the same ones.
+struct MemoHasher : TrHasher {
+    TrHasher& inner; std::map<std::string, std::vector<fr_t>> memo;
+    explicit MemoHasher(TrHasher& h) : inner(h) {}
+    int32_t hash(const char* tag, const fr_t* fields, size_t k, size_t n, fr_t* out) override {
+        std::string key(tag); key.push_back('\0'); key.append((const char*)&k, sizeof(k)); key.append((const char*)fields, k * n * sizeof(fr_t));
+        auto it = memo.find(key);
+        if (it == memo.end()) { std::vector<fr_t> v(n); int32_t rc = inner.hash(tag, fields, k, n, v.data()); if (rc) return rc; it = memo.emplace(std::move(key), std::move(v)).first; }
+        memcpy((void*)out, it->second.data(), n * sizeof(fr_t)); return 0;
+    }
+};
+// fri_prove_queries + payload assembly + canonical encoding (fri.rs:355-466, 613-640).  The indices of every opened value depend
+// only on the roots, so the query phase first RECORDS what it will read (fri_plan.hpp: the same code against a recording source),
+// fetches all of it — a few thousand layer elements and tree nodes spread over every layer and level — with ONE gather launch and
+// one download, and then assembles the proof from that list.  (One synchronisation instead of one per opened level.)
 static int32_t prove_queries_encode(stark_ctx* ctx, stark_fri_state* S, size_t n0, size_t r, stark_proof* P) {
-    FriShape sh; STARK_TRY(shape_of_state(ctx, S, n0, sh));
-    LocalSource src(ctx, S); DeviceHasher H(ctx);
-    int32_t rc = assemble_proof(sh, r, H, src, P->bytes, P->size_estimate);
-    if (rc == -1) return ctx->fail(STARK_ERR_INVALID_ARG, "query phase: bad index or short value list");
+    FriPlan plan; plan.r = r; STARK_TRY(shape_of_state(ctx, S, n0, plan.shape));
+    DeviceHasher H0(ctx); MemoHasher H(H0);
+    { int32_t rc = fri_plan_make(plan, H); if (rc == -1) return ctx->fail(STARK_ERR_INVALID_ARG, "query phase: bad index"); if (rc) return rc; }
+    const size_t nreq = plan.req.size();
+    std::vector<fr_t> vals(nreq);
+    if (nreq) {
+        // source table: layers first, then the levels of every tree
+        std::vector<const fr_t*> base; std::vector<size_t> lens; std::map<std::pair<uint32_t, uint32_t>, uint32_t> tree_slot;
+        for (size_t l = 0; l < S->f.size(); ++l) { base.push_back(S->f[l]); lens.push_back(S->n[l]); }
+        std::vector<uint32_t> src(nreq); std::vector<uint64_t> idx(nreq);
+        for (size_t i = 0; i < nreq; ++i) {
+            const FriRequest& q = plan.req[i];
+            if (q.kind == 0) { if (q.which >= S->f.size()) return ctx->fail(STARK_ERR_INVALID_ARG, "layer out of range"); src[i] = q.which; }
+            else {
+                if (q.which >= S->trees.size() || q.level >= S->trees[q.which]->levels.size()) return ctx->fail(STARK_ERR_INVALID_ARG, "tree level out of range");
+                auto key = std::make_pair(q.which, q.level); auto it = tree_slot.find(key);
+                if (it == tree_slot.end()) { it = tree_slot.emplace(key, (uint32_t)base.size()).first; base.push_back(S->trees[q.which]->levels[q.level]); lens.push_back(S->trees[q.which]->lens[q.level]); }
+                src[i] = it->second;
+            }
+            if (q.index >= lens[src[i]]) return ctx->fail(STARK_ERR_INVALID_ARG, "opening index out of range");
+            idx[i] = q.index;
+        }
+        DevBuf db, ds, di, dout;
+        STARK_HIP(ctx, db.alloc(ctx, base.size() * sizeof(void*))); STARK_HIP(ctx, ds.alloc(ctx, nreq * 4)); STARK_HIP(ctx, di.alloc(ctx, nreq * 8)); STARK_HIP(ctx, dout.alloc(ctx, nreq * sizeof(fr_t)));
+        STARK_HIP(ctx, hipMemcpyAsync(db.p, base.data(), base.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        STARK_HIP(ctx, hipMemcpyAsync(ds.p, src.data(), nreq * 4, hipMemcpyHostToDevice, ctx->stream));
+        STARK_HIP(ctx, hipMemcpyAsync(di.p, idx.data(), nreq * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gather_multi, dim3((unsigned)((nreq + 255) / 256)), dim3(256), 0, ctx->stream, (const fr_t* const*)db.p, (const uint32_t*)ds.p, (const uint64_t*)di.p, (uint64_t)nreq, dout.fr());
+        STARK_HIP(ctx, hipGetLastError());
+        STARK_HIP(ctx, hipMemcpyAsync(vals.data(), dout.p, nreq * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+        STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ReplaySource rep(vals.data(), vals.size());
+    int32_t rc = assemble_proof(plan.shape, r, H, rep, P->bytes, P->size_estimate);
+    if (rc == -1 || (rc == 0 && rep.pos != vals.size())) return ctx->fail(STARK_ERR_INVALID_ARG, "query phase: value list does not match the plan");
     return rc;
 }
 

@@ -135,6 +135,12 @@ static __global__ void k_gather(const fr_t* __restrict__ src, const uint64_t* __
     if (i < k) stg(out + i, ldg(src + idx[i]));
 }
 
+// Batched opening reads of the query phase: request i reads element index[i] of the array base[src[i]] (layers and tree levels of a
+// whole proof in ONE launch instead of one synchronised gather per level).
+static __global__ void k_gather_multi(const fr_t* const* __restrict__ base, const uint32_t* __restrict__ src, const uint64_t* __restrict__ index, uint64_t k, fr_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) stg(out + i, ldg(base[src[i]] + index[i]));
+}
 // dst[a][b][c] (contiguous, dims Da x Db x Dc) = src[a*sa + b*sb + c*sc]: the layout changes around the all-to-all exchanges
 // of the six-step NTT (32-byte elements, so even the transposing cases move whole 32-B units).
 static __global__ void k_permute3(const fr_t* __restrict__ src, fr_t* __restrict__ dst, uint64_t Da, uint64_t Db, uint64_t Dc, uint64_t sa, uint64_t sb, uint64_t sc) {

@@ -222,13 +222,17 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k
     __syncthreads();
     const size_t cnt = J.mode == 1 ? 2 : ((k + 1) * J.arity <= J.n_in ? J.arity : J.n_in - k * J.arity);
     const size_t total = 4 + cnt + 1, nperm = (total + rate - 1) / rate;
-    // the widest stream in the block decides how many absorb steps every lane walks through (barriers are
-    // wave-level: both waves of the pair must execute the same sequence of permutations)
+    // The widest stream in the block decides how many permutations every lane walks through (barriers are wave-level: both waves
+    // of the pair must execute the same sequence).  A lane with a SHORTER stream (the ragged last node of a level) sits out the
+    // first max_perm - nperm of them — it permutes a dead state, clears it, and starts absorbing late — so that EVERY lane's result
+    // is lane 0 of the last permutation: nothing has to be carried in registers across the permutations (the kernel sits at the
+    // 256-VGPR limit; carrying a per-lane result across pair_permute spilled 118 VGPRs to scratch).
     const size_t max_total = 4 + (J.mode == 1 ? 2 : J.arity) + 1, max_perm = (max_total + rate - 1) / rate;
+    const size_t skip = max_perm - nperm;
     size_t q = 0; fr_t res = fr_zero<PF>();
     for (size_t pidx = 0; pidx < max_perm; ++pidx) {
-        const bool active = pidx < nperm;
-        if (active) {
+        if (pidx >= skip) {
+            if (skip && pidx == skip) for (int j = o0; j < o1; ++j) s.sto(j, fr_zero<PF>());       // the dead permutations left garbage behind
             for (int cur = 0; cur < rate && q < total; ++cur, ++q) {
                 if (cur < o0 || cur >= o1) continue;
                 fr_t x;
@@ -239,9 +243,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k
             }
         }
         __syncthreads();
-        // lanes whose stream ended earlier keep their result and permute a dead state (values unused)
-        fr_t r2 = pair_permute<T>(s, P, pidx + 1 == max_perm);
-        if (active && pidx + 1 == nperm) res = (pidx + 1 == max_perm) ? r2 : s.ld(0);
+        res = pair_permute<T>(s, P, pidx + 1 == max_perm);
         __syncthreads();
     }
     if (live && !s.isY) stg(out + k0, res);
