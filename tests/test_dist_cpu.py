@@ -176,17 +176,17 @@ def _prove_worker(rank, world, port, log_n0, schedule, r, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("log_n0,schedule,r", [(9, [16, 8], 6), (10, [8, 8, 8], 5), (7, [16, 8], 3)])
-def test_sharded_prove_world2_matches_reference_bytes(log_n0, schedule, r):
-    """One trace block-sharded over 2 ranks -> the SAME canonical proof bytes as the oracle's prove of the whole trace."""
+@pytest.mark.parametrize("log_n0,schedule,r,world", [(9, [16, 8], 6, 2), (10, [8, 8, 8], 5, 2), (7, [16, 8], 3, 2), (10, [8, 8, 8], 4, 4)])
+def test_sharded_prove_world2_matches_reference_bytes(log_n0, schedule, r, world):
+    """One trace block-sharded over 2 (and 4) ranks -> the SAME canonical proof bytes as the oracle's prove of the whole trace."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + log_n0
-    procs = [ctx.Process(target=_prove_worker, args=(r_, 2, port, log_n0, schedule, r, q)) for r_ in range(2)]
+    port = 31500 + (os.getpid() % 2000) + log_n0 + 10 * world
+    procs = [ctx.Process(target=_prove_worker, args=(r_, world, port, log_n0, schedule, r, q)) for r_ in range(world)]
     for p in procs: p.start()
     res = [q.get(timeout=400) for _ in procs]
     for p in procs: p.join(60)
-    assert sorted(res) == [(0, True, True, 1), (1, True, True, 1)], res
+    assert sorted(res) == [(r_, True, True, 1) for r_ in range(world)], res
 
 
 def _lde_worker(rank, world, port, log_n, log_rows, q):
@@ -220,18 +220,18 @@ def _lde_worker(rank, world, port, log_n, log_rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("log_n,log_rows", [(7, 3), (8, 4)])
-def test_sharded_lde_and_chained_step_world2(log_n, log_rows):
-    """north_star's multi-GPU split on 2 ranks (gloo): the LDE of a block-sharded column through the six-step NTTs equals the
+@pytest.mark.parametrize("log_n,log_rows,world", [(7, 3, 2), (8, 4, 2), (8, 4, 4)])
+def test_sharded_lde_and_chained_step_world2(log_n, log_rows, world):
+    """north_star's multi-GPU split on 2 and 4 ranks (gloo): the LDE of a block-sharded column through the six-step NTTs equals the
     oracle's LDE of the whole column, and LDE -> merge -> sharded commit gives the oracle's roots for the whole trace."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + log_n
-    procs = [ctx.Process(target=_lde_worker, args=(r_, 2, port, log_n, log_rows, q)) for r_ in range(2)]
+    port = 33500 + (os.getpid() % 2000) + log_n + 10 * world
+    procs = [ctx.Process(target=_lde_worker, args=(r_, world, port, log_n, log_rows, q)) for r_ in range(world)]
     for p in procs: p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs: p.join(60)
-    assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
+    assert sorted(res) == [(r_, True, True, True) for r_ in range(world)], res
 
 
 def test_sharded_stop_len():
