@@ -27,6 +27,24 @@ __device__ __forceinline__ fr_t shfl_xor_fr(const fr_t& x, int mask) {
     for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_xor((int)x.v[i], mask, 64);
     return r;
 }
+__device__ __forceinline__ fr_t shfl_up_fr(const fr_t& x, int d) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_up((int)x.v[i], d, 64);
+    return r;
+}
+__device__ __forceinline__ fr_t shfl_dn_fr(const fr_t& x, int d) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], d, 64);
+    return r;
+}
+__device__ __forceinline__ fr_t shfl_idx_fr(const fr_t& x, int src) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl((int)x.v[i], src, 64);
+    return r;
+}
 #endif
 
 }  // namespace stark

@@ -53,9 +53,10 @@ __global__ void __launch_bounds__(256) k_fri_fold_any(const fr_t* __restrict__ f
 }
 
 // DEEP-ALI merge.  phi_j = a_j s_j + e_j - t_j (+ beta r_j);  f0_j = phi_j / (w^j - z).
-// Each lane owns K elements j = tid + u*T (T = total lanes) so loads stay coalesced; the K
-// denominators are inverted with ONE Fermat inversion (prefix products), as lib.rs's 2n inversions
-// are n independent field inverses whose values do not depend on how they are obtained.
+// Each lane owns K elements j = tid + u*T (T = total lanes) so loads stay coalesced; ALL 256*K denominators of a
+// workgroup are inverted with ONE Fermat inversion (Montgomery's trick, two levels: prefix products per lane, product
+// scans across the lanes), as lib.rs's 2n inversions are n independent field inverses whose values do not depend
+// on how they are obtained.
 // Also accumulates the barycentric partial sum  sum_j phi_j w^j / (z - w^j)  per block (for c*).
 #define ALI_K 8
 template <class F>
@@ -79,7 +80,33 @@ __global__ void __launch_bounds__(256) k_ali_merge(const fr_t* __restrict__ a, c
         pre[u] = run; run = fr_mul<F>(run, d);
         w = fr_mul<F>(w, w_step);
     }
-    fr_t inv = fr_inv<F>(run);                                     // one inversion per lane
+    // ONE Fermat inversion per WORKGROUP (it is ~380 products; per lane it would dwarf the ~9 products an element needs):
+    // wave-level inclusive prefix / suffix products of the lanes' `run` (shuffles), the four wave totals through LDS, wave 0 inverts
+    // their product, and every lane recovers  1/run = (1/P) * (other waves' totals) * (lanes before) * (lanes after).
+    __shared__ uint4 tot[2 * 4], pinv[2];
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = (int)(blockDim.x >> 6);
+    fr_t pre_i = run, suf_i = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const fr_t a = shfl_up_fr(pre_i, d), b = shfl_dn_fr(suf_i, d);
+        if (ln >= d) pre_i = fr_mul<F>(pre_i, a);
+        if (ln + d < 64) suf_i = fr_mul<F>(suf_i, b);
+    }
+    fr_t before = shfl_up_fr(pre_i, 1), after = shfl_dn_fr(suf_i, 1);
+    if (ln == 0) before = fr_one<F>();
+    if (ln == 63) after = fr_one<F>();
+    if (ln == 63) { tot[2 * wv] = make_uint4(pre_i.v[0], pre_i.v[1], pre_i.v[2], pre_i.v[3]); tot[2 * wv + 1] = make_uint4(pre_i.v[4], pre_i.v[5], pre_i.v[6], pre_i.v[7]); }
+    __syncthreads();
+    auto ld_tot = [&](const uint4* p, int i) { const uint4 lo = p[2 * i], hi = p[2 * i + 1]; fr_t x; x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w; return x; };
+    if (wv == 0) {
+        fr_t P = ld_tot(tot, 0); for (int i = 1; i < nwv; ++i) P = fr_mul<F>(P, ld_tot(tot, i));
+        const fr_t Pi = fr_inv<F>(P);
+        if (ln == 0) { pinv[0] = make_uint4(Pi.v[0], Pi.v[1], Pi.v[2], Pi.v[3]); pinv[1] = make_uint4(Pi.v[4], Pi.v[5], Pi.v[6], Pi.v[7]); }
+    }
+    __syncthreads();
+    fr_t inv = ld_tot(pinv, 0);
+    for (int i = 0; i < nwv; ++i) if (i != wv) inv = fr_mul<F>(inv, ld_tot(tot, i));                       // 1 / (this wave's total)
+    inv = fr_mul<F>(fr_mul<F>(inv, before), after);                                                       // 1 / run of this lane
     fr_t bary = fr_zero<F>();
 #pragma unroll
     for (int u = ALI_K - 1; u >= 0; --u) {                         // backward: peel the inverses off
@@ -90,7 +117,7 @@ __global__ void __launch_bounds__(256) k_ali_merge(const fr_t* __restrict__ a, c
             inv = fr_mul<F>(inv, fr_sub<F>(w, z));
             fr_t q = fr_mul<F>(phi[u], dinv);
             stg(f0 + j, q);
-            bary = fr_sub<F>(bary, fr_mul<F>(q, w));               // phi w^j / (z - w^j) = -(phi / (w^j - z)) w^j
+            if (block_sums) bary = fr_sub<F>(bary, fr_mul<F>(q, w));   // phi w^j / (z - w^j) = -(phi / (w^j - z)) w^j  (only when c* is asked for)
         }
     }
     if (block_sums) {
