@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps and the headline fields (for rocprofv3 kernel stats)")
     ap.add_argument("--e2e-log", type=int, default=20, help="log2 rows of the end-to-end deep_fri_prove section (0 disables)")
+    ap.add_argument("--synth-seed", type=lambda x: int(x, 0), default=None, help="seed of the synthetic trace (default 0x5EED0000 + log-trace); lets a 1-GPU run reproduce the trace of an N-GPU run")
     ap.add_argument("--csv", default=None, help="also write the reference's benchmarkdata.csv schema (end_to_end.rs:42-44) for the reference-input proves")
     args = ap.parse_args()
 
@@ -105,7 +106,7 @@ def main():
         return torch.empty((rows, 4), dtype=torch.int64, device=dev)
 
     # synthetic trace: columns 0..3; this rank holds rows [rank*n, (rank+1)*n) of the world*n-row trace (DESIGN.md "Synthetic inputs")
-    seed = 0x5EED0000 + log_n
+    seed = args.synth_seed if args.synth_seed is not None else 0x5EED0000 + log_n
     cols = [dbuf(n) for _ in range(4)]
     for c in range(4):
         ctx._chk(lib.stark_synth_column_dev(ctx.h, seed, c, rank * n, n, C.c_void_p(cols[c].data_ptr())))
