@@ -254,6 +254,13 @@ int32_t stark_fri_plan_requests(stark_fri_plan_t* p, uint32_t* kind, uint32_t* w
 int32_t stark_fri_plan_assemble(stark_fri_plan_t* p, const uint64_t* values, size_t n_values, stark_proof_t** out);
 int32_t stark_fri_plan_free(stark_fri_plan_t* p);
 
+/* ---- field helpers (crates/field/src/lib.rs) ------------------------------------------------------ */
+/* F::get_root_of_unity(2^log_n) — Domain::new's omega (field/src/lib.rs:43-53), FriDomain::new_radix2 (fri.rs:53-56).  Host-only. */
+int32_t stark_root_of_unity(int32_t field_id, size_t log_n, uint64_t* out4);
+/* compute_powers(base, n) = [1, base, ..., base^(n-1)] (field/src/lib.rs:125-133; Domain::precompute_elements with base = omega). */
+int32_t stark_compute_powers(stark_ctx_t* ctx, int32_t field_id, const uint64_t* base4, size_t n, uint64_t* out);
+int32_t stark_compute_powers_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* base4, size_t n, uint64_t* out);
+
 /* ---- NTT (crates/fft/src/lib.rs:6-32) ------------------------------------------------------------- */
 /* fft_in_place / ifft_in_place: natural order in and out; inverse != 0 includes the n^-1 scaling.
  * coset4 (optional): evaluate on coset4 * <w> (forward) / interpolate from it (inverse). */

@@ -106,6 +106,9 @@ SIGNATURES = {
     "stark_fri_plan_requests": (i32, [vp, vp, vp, vp, vp]),
     "stark_fri_plan_assemble": (i32, [vp, vp, sz, vpp]),
     "stark_fri_plan_free": (i32, [vp]),
+    "stark_root_of_unity": (i32, [i32, sz, vp]),
+    "stark_compute_powers": (i32, [vp, i32, vp, sz, vp]),
+    "stark_compute_powers_dev": (i32, [vp, i32, vp, sz, vp]),
     "stark_ntt": (i32, [vp, i32, vp, sz, i32, vp]),
     "stark_ntt_dev": (i32, [vp, i32, vp, sz, i32, vp]),
     "stark_lde": (i32, [vp, i32, vp, sz, sz, vp, vp]),

@@ -213,6 +213,15 @@ def ref_bench_inputs(seed, n, ncols=4):
     return out.reshape(ncols, n, 4)
 
 
+def root_of_unity(log_n, field=PALLAS_FR):
+    """F::get_root_of_unity(2^log_n) (host-only)."""
+    lib = load_library(); out = np.zeros(4, np.uint64)
+    rc = lib.stark_root_of_unity(field, log_n, _ptr(out))
+    if rc != 0:
+        raise StarkError(rc, "no root of unity of that order (two-adicity 32)")
+    return out
+
+
 class DeepFriParams:
     """fri.rs:589."""
 
@@ -498,6 +507,18 @@ class Context:
         h = C.c_void_p()
         self._chk(self.lib.stark_fri_plan_create(self.h, _ptr(rt), n0, _ptr(sch), len(sch), r, C.byref(h)))
         return FriQueryPlan(self, h)
+
+    # ---- field helpers (crates/field/src/lib.rs) ----------------------------------------------------------
+    def compute_powers(self, base, n, field=PALLAS_FR):
+        """compute_powers(base, n) (field/src/lib.rs:125-133)."""
+        out = np.zeros((n, 4), np.uint64)
+        self._chk(self.lib.stark_compute_powers(self.h, field, _ptr(_arr(base)), n, _ptr(out)))
+        return out
+
+    def domain(self, log_n, field=PALLAS_FR, precompute=False):
+        """Domain::new(log_n) (field/src/lib.rs:43-53): (size, log_n, omega[, elements])."""
+        w = root_of_unity(log_n, field)
+        return (1 << log_n, log_n, w, self.compute_powers(w, 1 << log_n, field) if precompute else None)
 
     # ---- fft (crates/fft/src/lib.rs:6-32) ------------------------------------------------------------
     def fft(self, coeffs, field=BLS12_381_FR, coset=None):

@@ -305,6 +305,43 @@ int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, s
     return STARK_OK;
 }
 
+// ---- crates/field: Domain::new / compute_powers (field/src/lib.rs:43-53, 125-133) ------------------------------------------------
+// get_root_of_unity(2^log_n) of the field (host-only: no context, no device)
+int32_t stark_root_of_unity(int32_t field_id, size_t log_n, uint64_t* out4) {
+    if (!out4 || log_n > 32) return STARK_ERR_INVALID_ARG;                                   // two-adicity 32 in both fields
+    if (field_id == STARK_FIELD_PALLAS_FR) store_fr(out4, fr_root_of_unity<PallasFr>((unsigned)log_n));
+    else if (field_id == STARK_FIELD_BLS12_381_FR) store_fr(out4, fr_root_of_unity<Bls12381Fr>((unsigned)log_n));
+    else return STARK_ERR_INVALID_ARG;
+    return STARK_OK;
+}
+template <class F> static int32_t powers_run(stark_ctx* ctx, const fr_t& base, size_t n, fr_t* out_dev) {
+    if (!n) return STARK_OK;
+    int bits = 1; while (((size_t)1 << bits) < n) ++bits;
+    const int lo_bits = (bits + 1) / 2, hi_bits = bits - lo_bits + 1;
+    DevTable T; STARK_TRY(fill_table<F>(ctx, base, fr_one<F>(), lo_bits, hi_bits, T));
+    hipLaunchKernelGGL(k_fill_pow_direct<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, T.view(), (uint64_t)n, out_dev);
+    hipError_t e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // the two-level table is a temporary of this call
+    (void)hipFree(T.lo); (void)hipFree(T.hi);
+    if (e != hipSuccess) return ctx->fail(STARK_ERR_HIP, "compute_powers");
+    return STARK_OK;
+}
+// compute_powers(base, n) = [1, base, ..., base^(n-1)] (also Domain::precompute_elements with base = omega); *_dev writes device memory
+int32_t stark_compute_powers_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* base4, size_t n, uint64_t* out) {
+    if (!ctx || !base4 || (!out && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    if (field_id == STARK_FIELD_PALLAS_FR) return powers_run<PallasFr>(ctx, load_fr(base4), n, as_fr(out));
+    if (field_id == STARK_FIELD_BLS12_381_FR) return powers_run<Bls12381Fr>(ctx, load_fr(base4), n, as_fr(out));
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+int32_t stark_compute_powers(stark_ctx_t* ctx, int32_t field_id, const uint64_t* base4, size_t n, uint64_t* out) {
+    if (!ctx || !base4 || (!out && n)) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    DevBuf d; STARK_HIP(ctx, d.alloc(ctx, n * sizeof(fr_t)));
+    STARK_TRY(stark_compute_powers_dev(ctx, field_id, base4, n, (uint64_t*)d.p));
+    if (n) STARK_HIP(ctx, hipMemcpyAsync(out, d.p, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+
 int32_t stark_synth_column_dev(stark_ctx_t* ctx, uint64_t seed, uint64_t col, size_t i0, size_t n, uint64_t* out) {
     if (!ctx || (!out && n)) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
