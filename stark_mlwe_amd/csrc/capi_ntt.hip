@@ -314,6 +314,7 @@ int32_t stark_root_of_unity(int32_t field_id, size_t log_n, uint64_t* out4) {
     else return STARK_ERR_INVALID_ARG;
     return STARK_OK;
 }
+}  // extern "C"
 template <class F> static int32_t powers_run(stark_ctx* ctx, const fr_t& base, size_t n, fr_t* out_dev) {
     if (!n) return STARK_OK;
     int bits = 1; while (((size_t)1 << bits) < n) ++bits;
@@ -325,6 +326,7 @@ template <class F> static int32_t powers_run(stark_ctx* ctx, const fr_t& base, s
     if (e != hipSuccess) return ctx->fail(STARK_ERR_HIP, "compute_powers");
     return STARK_OK;
 }
+extern "C" {
 // compute_powers(base, n) = [1, base, ..., base^(n-1)] (also Domain::precompute_elements with base = omega); *_dev writes device memory
 int32_t stark_compute_powers_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* base4, size_t n, uint64_t* out) {
     if (!ctx || !base4 || (!out && n)) return STARK_ERR_INVALID_ARG;
