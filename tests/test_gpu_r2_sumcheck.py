@@ -66,3 +66,20 @@ def test_transcript_object_matches_reference_flow(gpu_ctx, oracle):
     t = Transcript(gpu_ctx, b"chs"); many = t.challenges(b"r", 3); t.free()
     t = Transcript(gpu_ctx, b"chs"); one = [t.challenge(b"r" + i.to_bytes(8, "little")) for i in range(3)]; t.free()
     assert all((many[i] == one[i]).all() for i in range(3))                                                          # :103-112
+
+
+def test_field_crate_helpers(gpu_ctx, oracle):
+    """crates/field tests (field/src/lib.rs:217-280): Domain::new(log_n) has omega^n = 1 and omega^(n/2) != 1; compute_powers(base, n)
+    = [1, base, base^2, ...]; precomputed elements equal the powers of omega."""
+    from stark_mlwe_amd.api import BLS12_381_FR, PALLAS_FR
+    for field in (PALLAS_FR, BLS12_381_FR):
+        size, lg, w, el = gpu_ctx.domain(11, field, precompute=True)
+        assert size == 2048 and (oracle.pow(w, size, field) == oracle.from_u64(1, field)).all() and not (oracle.pow(w, size // 2, field) == oracle.from_u64(1, field)).all()
+        assert (el[0] == oracle.from_u64(1, field)).all() and (el[1] == w).all() and (el[2047] == oracle.pow(w, 2047, field)).all()
+        acc = oracle.from_u64(1, field)
+        for i in range(40):
+            assert (el[i] == acc).all(); acc = oracle.mul(acc, w, field)
+    b = oracle.from_u64(3)
+    p = gpu_ctx.compute_powers(b, 1000)
+    assert (p[999] == oracle.pow(b, 999)).all() and (p[0] == oracle.from_u64(1)).all()
+    assert gpu_ctx.compute_powers(b, 0).shape == (0, 4)
