@@ -456,6 +456,14 @@ class Context:
         return bool(ok.value)
 
     # ---- sum-check consumer (channel/src/lib.rs:1045-1240) ------------------------------------------------
+    def mle_evaluate(self, table, r):
+        """Mle::new(table).evaluate(r) (channel/src/lib.rs:279-295)."""
+        t, rr = _arr(table), _arr(r).reshape(-1, 4); out = np.zeros(4, np.uint64)
+        if t.shape[0] != 1 << rr.shape[0]:
+            raise StarkError(-1, "dimension mismatch")
+        self._chk(self.lib.stark_mle_evaluate(self.h, _ptr(t), rr.shape[0], _ptr(rr), _ptr(out)))
+        return out
+
     def prove_plain(self, k, tree_label, witness):
         """prove_plain(&build_vk_plain(k, F::from(tree_label)), witness) -> bincode-layout ProofPlain bytes."""
         w = _arr(witness); h = C.c_void_p()

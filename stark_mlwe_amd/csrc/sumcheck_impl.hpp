@@ -427,6 +427,19 @@ int32_t stark_ref_bench_inputs(uint64_t seed, size_t n, size_t ncols, uint64_t* 
     return STARK_OK;
 }
 
+// Mle::evaluate(r) (channel/src/lib.rs:279-295): k folds layer[i] = (1 - r_j) layer[2i] + r_j layer[2i+1]; table of 2^k elements (host).
+int32_t stark_mle_evaluate(stark_ctx_t* ctx, const uint64_t* table, size_t k, const uint64_t* r, uint64_t* out4) {
+    if (!ctx || !table || (!r && k) || !out4 || k > 40) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const size_t n = (size_t)1 << k;
+    DevBuf a, b; STARK_HIP(ctx, a.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, b.alloc(ctx, std::max<size_t>(n / 2, 1) * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(a.p, table, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    fr_t* cur = a.fr(); fr_t* nxt = b.fr(); size_t len = n;
+    for (size_t j = 0; j < k; ++j) { STARK_TRY(fold(ctx, cur, len, load_fr(r + 4 * j), nxt)); std::swap(cur, nxt); len /= 2; }
+    fr_t v; STARK_HIP(ctx, hipMemcpyAsync(&v, cur, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    store_fr(out4, v); return STARK_OK;
+}
+
 int32_t stark_sumcheck_prove_plain_dev(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, stark_proof_t** out) {
     if (!ctx || !witness || !out) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
