@@ -83,3 +83,28 @@ def test_field_crate_helpers(gpu_ctx, oracle):
     p = gpu_ctx.compute_powers(b, 1000)
     assert (p[999] == oracle.pow(b, 999)).all() and (p[0] == oracle.from_u64(1)).all()
     assert gpu_ctx.compute_powers(b, 0).shape == (0, 4)
+
+
+def test_channel_roundtrips_composed_from_the_abi(gpu_ctx, oracle):
+    """e2e_merkle_channel_roundtrip and e2e_mle_commit_eval_roundtrip (channel/src/lib.rs:1253-1336) composed from the exported pieces:
+    prover and verifier transcripts fed the same messages draw the same challenges; the commitment is MerkleCommitment's; the MLE
+    evaluation at the drawn point equals the oracle's."""
+    from stark_mlwe_amd.api import MerkleChannelCfg, Transcript
+    table = oracle.rand_fr_columns(999, 32, 1)[0]
+    seedp = gpu_ctx.generate_params_t17_x5(b"POSEIDON-T17-X5-SEED")
+    cfg = MerkleChannelCfg(16, seedp, 3030)                                   # MerkleCommitment::tree_cfg (commitment/src/lib.rs:65-73)
+    tree = gpu_ctx.merkle_new(table, cfg); root = tree.root()
+    assert (root == oracle.commitment_root(3030, table)).all()
+    tp, tv = Transcript(gpu_ctx, b"MLE-CHAN-E2E"), Transcript(gpu_ctx, b"MLE-CHAN-E2E")
+    for t in (tp, tv):                                                        # send_digest / recv_digest (:22-26, :77-81)
+        t.absorb_bytes(b"CHAN/SEND/DIGEST"); t.absorb_bytes(b"commit/root"); t.absorb_fields(root)
+    r_p = np.stack([tp.challenge(b"r" + j.to_bytes(8, "little")) for j in range(5)])      # MleProver::draw_point (:315-324)
+    r_v = np.stack([tv.challenge(b"r" + j.to_bytes(8, "little")) for j in range(5)])
+    assert (r_p == r_v).all()
+    val = gpu_ctx.mle_evaluate(table, r_p)
+    assert (val == oracle.mle_evaluate(table, r_p)).all()
+    idx = [0, 1, 2, 31]
+    pr = tree.open_many(idx)
+    # the generic verifier derives poseidon_params_for_arity(16) — other constants than MerkleCommitment's — and must refuse this tree
+    assert gpu_ctx.merkle_verify_single(gpu_ctx.merkle_cfg(16, 3030), root, idx, table[idx], pr) is False
+    tree.free(); tp.free(); tv.free(); seedp.free()
