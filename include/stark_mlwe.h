@@ -210,6 +210,11 @@ int32_t stark_merkle_verify_pairs_ds(stark_ctx_t* ctx, size_t cfg_arity, uint64_
  * the Fiat-Shamir channel (:7-117) is a device-resident transcript.  The proof comes back as a stark_proof_t whose bytes are the
  * bincode 1.x layout of the reference's serde structs ProofPlain / ProofMF (:925-979) — read them with stark_proof_len /
  * stark_proof_bytes.  verify_*: *accepted = 1 / 0; a failed round check (an assert_eq! panic in the reference) is a rejection. */
+/* trait CommitmentScheme for MerkleCommitment (commitment/src/lib.rs:13-27, 80-114): commit (arity 16, tree_label = ds_tag, parameters
+ * "POSEIDON-T17-X5-SEED") -> a tree handle (root: stark_merkle_root; open: stark_merkle_open); verify over the bytes of stark_merkle_open. */
+int32_t stark_commitment_commit(stark_ctx_t* ctx, uint64_t ds_tag, const uint64_t* leaves, size_t n, stark_tree_t** out);
+int32_t stark_commitment_verify(stark_ctx_t* ctx, uint64_t ds_tag, const uint64_t* root4, const size_t* indices, size_t k, const uint64_t* values,
+                                const uint8_t* proof, size_t len, int32_t* accepted);
 /* Mle::evaluate (channel/src/lib.rs:279-295): the multilinear extension of a 2^k table at r (k elements); host pointers. */
 int32_t stark_mle_evaluate(stark_ctx_t* ctx, const uint64_t* table, size_t k, const uint64_t* r, uint64_t* out4);
 int32_t stark_sumcheck_prove_plain(stark_ctx_t* ctx, const uint64_t* witness, size_t k, uint64_t tree_label, stark_proof_t** out);

@@ -92,6 +92,8 @@ SIGNATURES = {
     "stark_deep_fri_verify": (i32, [vp, vp, sz, vp, sz, sz, u64, C.POINTER(i32)]),
     "stark_merkle_verify_many_ds": (i32, [vp, sz, u64, vp, vp, sz, vp, vp, sz, C.POINTER(i32)]),
     "stark_merkle_verify_pairs_ds": (i32, [vp, sz, u64, vp, vp, sz, vp, vp, vp, sz, C.POINTER(i32)]),
+    "stark_commitment_commit": (i32, [vp, u64, vp, sz, vpp]),
+    "stark_commitment_verify": (i32, [vp, u64, vp, vp, sz, vp, vp, sz, C.POINTER(i32)]),
     "stark_mle_evaluate": (i32, [vp, vp, sz, vp, vp]),
     "stark_sumcheck_prove_plain": (i32, [vp, vp, sz, u64, vpp]),
     "stark_sumcheck_prove_plain_dev": (i32, [vp, vp, sz, u64, vpp]),

@@ -456,6 +456,20 @@ class Context:
         return bool(ok.value)
 
     # ---- sum-check consumer (channel/src/lib.rs:1045-1240) ------------------------------------------------
+    def commitment_commit(self, ds_tag, leaves):
+        """MerkleCommitment::new(MerkleConfig::with_default_params(ds_tag)).commit(leaves) -> (root, tree) (commitment/src/lib.rs:85-90)."""
+        lv = _arr(leaves); h = C.c_void_p()
+        self._chk(self.lib.stark_commitment_commit(self.h, ds_tag, _ptr(lv), lv.shape[0] if lv.size else 0, C.byref(h)))
+        t = MerkleTree(self, h, MerkleChannelCfg(16, None, ds_tag))
+        return t.root(), t
+
+    def commitment_verify(self, ds_tag, root, indices, values, proof: bytes) -> bool:
+        """CommitmentScheme::verify (commitment/src/lib.rs:96-113)."""
+        ix = np.ascontiguousarray(indices, dtype=np.uint64); v = _arr(values)
+        buf = (C.c_uint8 * max(1, len(proof))).from_buffer_copy(proof or b"\0"); ok = C.c_int32(0)
+        self._chk(self.lib.stark_commitment_verify(self.h, ds_tag, _ptr(_arr(root)), _ptr(ix), len(ix), _ptr(v), buf, len(proof), C.byref(ok)))
+        return bool(ok.value)
+
     def mle_evaluate(self, table, r):
         """Mle::new(table).evaluate(r) (channel/src/lib.rs:279-295)."""
         t, rr = _arr(table), _arr(r).reshape(-1, 4); out = np.zeros(4, np.uint64)

@@ -427,6 +427,29 @@ int32_t stark_ref_bench_inputs(uint64_t seed, size_t n, size_t ncols, uint64_t* 
     return STARK_OK;
 }
 
+// CommitmentScheme for MerkleCommitment (commitment/src/lib.rs:80-114): arity 16, tree_label = cfg.ds_tag, parameters "POSEIDON-T17-X5-SEED".
+int32_t stark_commitment_commit(stark_ctx_t* ctx, uint64_t ds_tag, const uint64_t* leaves, size_t n, stark_tree_t** out) {
+    if (!ctx || !leaves || !out) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    stark_params* cp = nullptr; STARK_TRY(commit_params(ctx, &cp));
+    DevBuf d; STARK_HIP(ctx, d.alloc(ctx, std::max<size_t>(n, 1) * sizeof(fr_t)));
+    if (n) STARK_HIP(ctx, hipMemcpyAsync(d.p, leaves, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(merkle_build_on(ctx, ctx->stream, cp, 16, ds_tag, d.fr(), n, 0, nullptr, 1, 0, 0, 0, false, out));     // commit (:85-90); open = stark_merkle_open (:92-94)
+    STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK;
+}
+// verify (:96-113): verify_many_ds with the static t = 17 parameters lifted to the dynamic form
+int32_t stark_commitment_verify(stark_ctx_t* ctx, uint64_t ds_tag, const uint64_t* root4, const size_t* indices, size_t k, const uint64_t* values, const uint8_t* proof, size_t len, int32_t* accepted) {
+    if (!ctx || !root4 || (!indices && k) || (!values && k) || (!proof && len) || !accepted) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    *accepted = 0;
+    ByteReader R(proof, len); MerkleProofHost pr; if (!dec_mproof(R, pr) || R.left()) return STARK_OK;
+    stark_params* cp = nullptr; STARK_TRY(commit_params(ctx, &cp));
+    std::vector<size_t> ix(indices, indices + k); std::vector<fr_t> v(k); for (size_t i = 0; i < k; ++i) v[i] = load_fr(values + 4 * i);
+    CommitVerifyHasher H(ctx, cp); bool ok = false;
+    STARK_TRY(verify_many_ds_host(H, 16, load_fr(root4), ix, v, pr, ds_tag, ok));
+    *accepted = ok ? 1 : 0; return STARK_OK;
+}
+
 // Mle::evaluate(r) (channel/src/lib.rs:279-295): k folds layer[i] = (1 - r_j) layer[2i] + r_j layer[2i+1]; table of 2^k elements (host).
 int32_t stark_mle_evaluate(stark_ctx_t* ctx, const uint64_t* table, size_t k, const uint64_t* r, uint64_t* out4) {
     if (!ctx || !table || (!r && k) || !out4 || k > 40) return STARK_ERR_INVALID_ARG;

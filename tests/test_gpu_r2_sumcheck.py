@@ -108,3 +108,17 @@ def test_channel_roundtrips_composed_from_the_abi(gpu_ctx, oracle):
     # the generic verifier derives poseidon_params_for_arity(16) — other constants than MerkleCommitment's — and must refuse this tree
     assert gpu_ctx.merkle_verify_single(gpu_ctx.merkle_cfg(16, 3030), root, idx, table[idx], pr) is False
     tree.free(); tp.free(); tv.free(); seedp.free()
+
+
+def test_commitment_scheme_roundtrip(gpu_ctx, oracle):
+    """commitment/src/lib.rs:121-136 (merkle_commit_open_verify_roundtrip): n = 64 leaves, ds_tag 123, indices [0,15,16,31,47,63];
+    plus the channel test's ragged n = 55 (channel/src/lib.rs:1264-1281)."""
+    for n, ds, idx in ((64, 123, [0, 15, 16, 31, 47, 63]), (55, 2025, [0, 3, 7, 11, 54])):
+        leaves = oracle.rand_fr_columns(42, n, 1)[0]
+        root, tree = gpu_ctx.commitment_commit(ds, leaves)
+        assert (root == oracle.commitment_root(ds, leaves)).all()
+        pr = tree.open_many(idx); tree.free()
+        assert gpu_ctx.commitment_verify(ds, root, idx, leaves[idx], pr) is True
+        bad = leaves[idx].copy(); bad[2, 1] ^= np.uint64(1)
+        assert gpu_ctx.commitment_verify(ds, root, idx, bad, pr) is False
+        assert gpu_ctx.commitment_verify(ds + 1, root, idx, leaves[idx], pr) is False
