@@ -94,7 +94,7 @@ template <class F> __device__ __forceinline__ fr29_t ld29(const uint32_t* p) {  
     for (int i = 0; i < 9; ++i) r.l[i] = p ? p[i] : 0u;
     return r;
 }
-struct CoopLds { uint32_t* mds; uint4* x; };   // [T*T][9] (nine 29-bit limbs, 2^261 domain, x 2^20), [T][2] (packed elements)
+struct CoopLds { uint32_t* mds; uint32_t* x; };   // [T*T][9] (nine 29-bit limbs, 2^261 domain, x 2^20), [T][9] (S-box outputs as nine 29-bit limbs)
 __device__ __forceinline__ fr_t lds_get(const uint4* base, int idx) {
     uint4 lo = base[2 * idx], hi = base[2 * idx + 1];
     fr_t x; x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w; return x;
@@ -104,14 +104,14 @@ __device__ __forceinline__ void lds_put(uint4* base, int idx, const fr_t& x) {
 }
 // LDS: x first (16-byte slots), then M as plain words, 36 B per entry (10.7 KiB for t = 17: LDS never limits the number of
 // one-wave workgroups per CU).  B_1*M is used by ONE of the eight full rounds and is read from global memory there.
-static inline size_t coop_lds_bytes(int t) { return (size_t)t * 2 * 16 + (size_t)t * t * 9 * 4; }
+static inline size_t coop_lds_bytes(int t) { return (size_t)(t * 9 + 3) / 4 * 16 + (size_t)t * t * 9 * 4; }
 __device__ __forceinline__ void lds_get29(const uint32_t* base, int idx, uint32_t* a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) a[i] = base[9 * idx + i];
 }
 template <int T> __device__ __forceinline__ CoopLds coop_setup(uint4* lds, const PoseidonDev& P) {
-    uint32_t* m = reinterpret_cast<uint32_t*>(lds + T * 2);
-    CoopLds L{m, lds};
+    uint32_t* m = reinterpret_cast<uint32_t*>(lds + (T * 9 + 3) / 4);
+    CoopLds L{m, reinterpret_cast<uint32_t*>(lds)};
     for (int k = threadIdx.x; k < T * T * 9; k += 64) L.mds[k] = P.mds29[k];                                    // coalesced word copies
     __syncthreads();
     return L;
@@ -127,7 +127,14 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
     const int j0 = q * PER, j1 = (j0 + PER < T) ? j0 + PER : T;
     const bool elem = lane < T;
     auto full_round = [&](int r, const uint32_t* M, const bool in_lds) {
-        if (elem) { s = fr_pow5_r29<PF>(fr_add<PF>(s, ldg(P.rc_full + r * T + lane))); lds_put(L.x, lane, s); }    // x^5 / 2^20: the matrices carry the 2^20
+        // S-box on the element lanes; the result stays in nine-limb form (below 1.01 r: a valid multiplier operand) and goes to LDS
+        // as such — no pack / conditional subtraction here, no unpack in front of each of the row segment's terms
+        if (elem) {
+            const fr29_t u = fr29_unpack(fr_add<PF>(s, ldg(P.rc_full + r * T + lane)));
+            const fr29_t x2 = fr29_sqr_mont<PF>(u), x4 = fr29_sqr_mont<PF>(x2), x5 = fr29_mul_mont<PF>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
+#pragma unroll
+            for (int i = 0; i < 9; ++i) L.x[9 * lane + i] = x5.l[i];
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         fr_t part = fr_zero<PF>();
@@ -138,7 +145,10 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
                 uint32_t a[9];
                 if (in_lds) lds_get29(M, row * T + j, a);
                 else { _Pragma("unroll") for (int i = 0; i < 9; ++i) a[i] = P.mds_pre29[9 * (row * T + j) + i]; }
-                fr_wide29_mac_regs(acc, a, fr29_unpack(lds_get(L.x, j)));
+                fr29_t xj;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) xj.l[i] = L.x[9 * j + i];
+                fr_wide29_mac_regs(acc, a, xj);
             }
             part = fr_wide29_reduce<PF>(acc);
         }
