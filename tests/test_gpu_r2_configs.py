@@ -48,6 +48,27 @@ def test_end_to_end_prove_matches_oracle_golden(gpu_ctx, k, r):
     assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
 
 
+@pytest.mark.skipif(os.environ.get("STARK_LONG_TESTS") != "1", reason="2.6 GPU-minutes (155 s of serial column sponge): run with STARK_LONG_TESTS=1; the recorded run is profiles/r02_prove_2pow24_end_to_end.json")
+def test_end_to_end_prove_2pow24_matches_oracle_golden(gpu_ctx):
+    """north_star's target size on ONE GPU: `stark_deep_fri_prove_dev` of a 2^24-row trace (r = 40, [16,16,8]) from (a, s, e, t), proof
+    bytes against the golden the CPU oracle produced (tests/golden/proof_k24_r40.json, tools/gen_golden.py 24:40 — about two hours of 8 cores)."""
+    path = os.path.join(GOLD, "proof_k24_r40.json")
+    if not os.path.exists(path):
+        pytest.skip("golden for 2^24 not generated")
+    gold = json.load(open(path))
+    n0 = 1 << 24
+    cols = _dev_cols(gpu_ctx, gold["synth_seed"], n0)
+    sch = np.ascontiguousarray(SCHED, dtype=np.uint64); h = C.c_void_p()
+    gpu_ctx._chk(gpu_ctx.lib.stark_deep_fri_prove_dev(gpu_ctx.h, *[C.c_void_p(c.data_ptr()) for c in cols], None, n0, sch.ctypes.data_as(C.c_void_p), 3, 40, SEED_Z, C.byref(h)))
+    ms = [gpu_ctx.lib.stark_proof_stage_ms(h, i) for i in range(3)]
+    proof, est = gpu_ctx._proof_out(h)
+    rec = {"log_n0": 24, "r": 40, "proof_len": len(proof), "size_estimate": est, "sha256": hashlib.sha256(proof).hexdigest(), "golden_sha256": gold["sha256"],
+           "build_f0_ms": ms[0], "fri_build_ms": ms[1], "queries_encode_ms": ms[2], "matches_golden": hashlib.sha256(proof).hexdigest() == gold["sha256"]}
+    out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, "prove_2pow24_end_to_end.json"), "w"), indent=1)
+    assert len(proof) == gold["proof_len"] and est == gold["size_estimate"] and rec["matches_golden"]
+
+
 @pytest.mark.parametrize("k,want_est,want_len", [(12, 52000, 55633), (13, 60968, 64844), (14, 72936, 76973), (15, 87736, 91998), (16, 101976, 106420)])
 def test_published_fingerprints_k12_to_k16_on_gpu(gpu_ctx, oracle, k, want_est, want_len):
     """The reference's own bench inputs (end_to_end.rs:214, 229-253: seed chain from 1337, one LCG step per (preset, k),
