@@ -89,7 +89,21 @@ FR_HD void fr_wide29_norm(fr_wide29& w) {
 }
 // Montgomery step: divides the column sums by R' = 2^261; l[0..8] = limbs of the quotient (l[8] keeps every bit
 // above 2^232).  For a sum of K products of operands below 2r the quotient is below (K/32 + 1) r.
-template <class F> FR_HD void fr_wide29_mont(fr_wide29& w, uint32_t* l) {
+// MAC_POW2: a power-of-two limb of the modulus (Pallas: limb 8 = 2^22) is normally strength-reduced to a 64-bit shift plus a 64-bit
+// add (two full-rate instructions per digit) — right for the throughput kernels, whose multiplier pipe is the saturated resource
+// (measured: leaf kernel 3 % SLOWER with the MAC form).  On a lone wave every instruction costs one ~5-cycle issue slot, so the
+// latency kernels (poseidon_coop.hpp) hold the limb in a register as an opaque multiplier: ONE v_mad_u64_u32 per digit instead of two
+// instructions (sponge 145.6 -> 141.9 us per permutation).
+template <class F, bool MAC_POW2 = false> FR_HD void fr_wide29_mont(fr_wide29& w, uint32_t* l) {
+    uint32_t pj[9];
+#pragma unroll
+    for (int j = 1; j < 9; ++j) pj[j] = fr_p29<F>(j);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MAC_POW2) {
+#pragma unroll
+        for (int j = 1; j < 9; ++j) if (fr_p29<F>(j) != 0 && (fr_p29<F>(j) & (fr_p29<F>(j) - 1)) == 0) asm("" : "+v"(pj[j]));
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const uint64_t t = w.c[k];
@@ -97,7 +111,7 @@ template <class F> FR_HD void fr_wide29_mont(fr_wide29& w, uint32_t* l) {
         w.c[k + 1] += (t + m) >> 29;
 #pragma unroll
         for (int j = 1; j < 9; ++j)
-            if (fr_p29<F>(j) != 0) w.c[k + j] += (uint64_t)m * fr_p29<F>(j);
+            if (fr_p29<F>(j) != 0) w.c[k + j] += (uint64_t)m * pj[j];
     }
     uint64_t carry = 0;
 #pragma unroll
@@ -122,8 +136,8 @@ template <class F> FR_HD fr_t fr29_pack_reduce(const uint32_t* l) {
     return z;
 }
 // Montgomery reduction by R' = 2^261 and return to eight 32-bit limbs, fully reduced.
-template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
-    uint32_t l[9]; fr_wide29_mont<F>(w, l);
+template <class F, bool MAC_POW2 = false> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
+    uint32_t l[9]; fr_wide29_mont<F, MAC_POW2>(w, l);
     return fr29_pack_reduce<F>(l);
 }
 
@@ -134,7 +148,7 @@ template <class F> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
 // between the three steps; each step divides by R' = 2^261 while the operands carry R = 2^256, so the result is
 //     fr_pow5_r29(x R) = x^5 R / 2^20      (three times a factor 2^5, compounded: 2^-5, 2^-15, 2^-20)
 // and every constant that multiplies an S-box output is stored pre-multiplied by 2^20 (host_util.hpp to_radix29).
-template <class F> FR_HD fr29_t fr29_sqr_mont(const fr29_t& a) {
+template <class F, bool MAC_POW2 = false> FR_HD fr29_t fr29_sqr_mont(const fr29_t& a) {
     fr_wide29 w; fr_wide29_zero(w);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -142,15 +156,15 @@ template <class F> FR_HD fr29_t fr29_sqr_mont(const fr29_t& a) {
 #pragma unroll
         for (int j = i + 1; j < 9; ++j) w.c[i + j] += (uint64_t)a.l[i] * (a.l[j] << 1);
     }
-    fr29_t r; fr_wide29_mont<F>(w, r.l); return r;
+    fr29_t r; fr_wide29_mont<F, MAC_POW2>(w, r.l); return r;
 }
-template <class F> FR_HD fr29_t fr29_mul_mont(const fr29_t& a, const fr29_t& b) {
+template <class F, bool MAC_POW2 = false> FR_HD fr29_t fr29_mul_mont(const fr29_t& a, const fr29_t& b) {
     fr_wide29 w; fr_wide29_zero(w);
 #pragma unroll
     for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int j = 0; j < 9; ++j) w.c[i + j] += (uint64_t)a.l[i] * b.l[j];
-    fr29_t r; fr_wide29_mont<F>(w, r.l); return r;
+    fr29_t r; fr_wide29_mont<F, MAC_POW2>(w, r.l); return r;
 }
 constexpr int FR29_SBOX_SHIFT = 20;
 template <class F> FR_HD fr_t fr_pow5_r29(const fr_t& x) {

@@ -131,7 +131,7 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
         // as such — no pack / conditional subtraction here, no unpack in front of each of the row segment's terms
         if (elem) {
             const fr29_t u = fr29_unpack(fr_add<PF>(s, ldg(P.rc_full + r * T + lane)));
-            const fr29_t x2 = fr29_sqr_mont<PF>(u), x4 = fr29_sqr_mont<PF>(x2), x5 = fr29_mul_mont<PF>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
+            const fr29_t x2 = fr29_sqr_mont<PF, true>(u), x4 = fr29_sqr_mont<PF, true>(x2), x5 = fr29_mul_mont<PF, true>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
 #pragma unroll
             for (int i = 0; i < 9; ++i) L.x[9 * lane + i] = x5.l[i];
         }
@@ -150,7 +150,7 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
                 for (int i = 0; i < 9; ++i) xj.l[i] = L.x[9 * j + i];
                 fr_wide29_mac_regs(acc, a, xj);
             }
-            part = fr_wide29_reduce<PF>(acc);
+            part = fr_wide29_reduce<PF, true>(acc);
         }
         fr_t tot = part;
 #pragma unroll
@@ -191,7 +191,7 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
         {   // D_q = sum_j u_{q,j} s_j from the block-start lanes
             const int dq = lane >> LOG_RATE, dj = 1 + (lane & (RATE - 1));
             const fr29_t sj = shfl29(sl, dj);
-            fr29_t v = fr29_mul_mont<PF>(ld29<PF>(dq < 4 ? c29(P.sparse29, r0 + dq * w + dj) : nullptr), sj);   // u_{q,j}: not scaled
+            fr29_t v = fr29_mul_mont<PF, true>(ld29<PF>(dq < 4 ? c29(P.sparse29, r0 + dq * w + dj) : nullptr), sj);   // u_{q,j}: not scaled
             int pending = 0;
 #pragma unroll
             for (int d = RATE / 2; d >= 1; d >>= 1) { v = add29(v, shfl_xor29(v, d)); if (++pending == 2) { carry29(v); pending = 0; } }
@@ -211,10 +211,10 @@ __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const
             const fr29_t x = s0l;                                   /* s0 + c: the constant is already in (block start) */ \
             fr29_t a1;                                                                            \
             _Pragma("unroll") for (int i = 0; i < 9; ++i) a1.l[i] = sq_lane ? x.l[i] : cst[q].l[i]; \
-            const fr29_t m1 = fr29_mul_mont<PF>(a1, x);                        /* slot 1 */         \
+            const fr29_t m1 = fr29_mul_mont<PF, true>(a1, x);                        /* slot 1 */         \
             const fr29_t x2 = bcast29(m1, 48);                                                    \
-            const fr29_t x4 = fr29_sqr_mont<PF>(x2);                           /* slot 2 */         \
-            const fr29_t m3 = fr29_mul_mont<PF>(m1, x4);                       /* slot 3 (zero where cst is zero) */ \
+            const fr29_t x4 = fr29_sqr_mont<PF, true>(x2);                           /* slot 2 */         \
+            const fr29_t m3 = fr29_mul_mont<PF, true>(m1, x4);                       /* slot 3 (zero where cst is zero) */ \
             sl = add29(sl, m3); carry29(sl);                                                      \
             s0l = bcast29(sl, 32 + q);                                                            \
         }
