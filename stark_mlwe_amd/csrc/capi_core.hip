@@ -221,6 +221,7 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     if (stream == STARK_STREAM_PRIVATE) { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return STARK_ERR_HIP; } c->own_stream = true; }
     else { c->stream = (hipStream_t)stream; c->own_stream = false; }         // NULL = the device's legacy default stream (ordered against torch's default stream and every blocking stream)
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return STARK_ERR_HIP; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
     stark::ntt_set_attrs();
     // allow the full 160 KiB of LDS per workgroup for the kernels that stage through it
     (void)hipFuncSetAttribute((const void*)k_leaf_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);

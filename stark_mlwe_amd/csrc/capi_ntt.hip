@@ -40,6 +40,13 @@ static const size_t kMaxLds = 160 * 1024;
 // n*32 B of HBM per strided pass and plan, which the VALU-bound transform does not notice, and save a product per element and pass
 static inline int ntt_direct_max(const stark_ctx* ctx) { return ctx->opt_ntt_direct_max_log; }
 
+// The NTT kernels multiply by table entries with ONE Montgomery step by 2^261 on nine-limb values (ntt_dev.hpp): every table
+// of a plan carries the factor 32 that makes that step a product in the 2^256 domain.
+template <class F> static inline fr_t x32(const fr_t& v) { return fr_mul<F>(v, fr_from_u64<F>(32)); }
+template <class F> static inline void pass_consts(NttPassArgs& A) {
+    ntt29_offset<F>(A.dlimb);
+}
+
 template <class F>
 static int32_t fill_table(stark_ctx* ctx, const fr_t& g, const fr_t& c0, int lo_bits, int hi_bits, DevTable& T) {
     if (T.lo) { (void)hipFree(T.lo); T.lo = nullptr; } if (T.hi) { (void)hipFree(T.hi); T.hi = nullptr; }
@@ -62,10 +69,10 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
     auto bail = [&](int32_t rc) { delete p; return rc; };
     fr_t w = fr_root_of_unity<F>((unsigned)log_n); if (inverse) w = fr_inv<F>(w);
     int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
-    { int32_t rc = fill_table<F>(ctx, w, fr_one<F>(), lo_bits, hi_bits, p->root); if (rc) return bail(rc); }
+    { int32_t rc = fill_table<F>(ctx, w, x32<F>(fr_one<F>()), lo_bits, hi_bits, p->root); if (rc) return bail(rc); }
     for (int i = 0; i < p->P; ++i) {
         int lb = p->log_b[i]; fr_t wb = fr_root_of_unity<F>((unsigned)lb); if (inverse) wb = fr_inv<F>(wb);
-        DevTable T; int32_t rc = fill_table<F>(ctx, wb, fr_one<F>(), lb > 0 ? lb - 1 : 0, 0, T); if (rc) return bail(rc);
+        DevTable T; int32_t rc = fill_table<F>(ctx, wb, x32<F>(fr_one<F>()), lb > 0 ? lb - 1 : 0, 0, T); if (rc) return bail(rc);
         p->stage_tw[i] = T.lo; (void)hipFree(T.hi);
     }
     if (ntt_direct_max(ctx) >= log_n) {       // direct twiddle tables: 2^log_m entries per strided pass
@@ -77,7 +84,7 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
         }
     }
     if (inverse) {
-        fr_t ninv = fr_inv<F>(fr_from_u64<F>(1ull << log_n));
+        fr_t ninv = x32<F>(fr_inv<F>(fr_from_u64<F>(1ull << log_n)));
         if (hipMalloc((void**)&p->scale, sizeof(fr_t)) != hipSuccess) return bail(ctx->fail(STARK_ERR_OOM, "ntt scale"));
         if (hipMemcpyAsync(p->scale, &ninv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "ntt scale copy"));
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(ctx->fail(STARK_ERR_HIP, "sync"));
@@ -85,7 +92,7 @@ static int32_t get_plan(stark_ctx* ctx, int log_n, bool inverse, NttPlan** out) 
     ctx->plans[key] = p; *out = p; return STARK_OK;
 }
 
-static inline size_t ntt_lds_bytes(int log_b, int log_c) { return (((size_t)2 << (log_b + log_c)) + ((size_t)1 << log_b)) * 16; }
+static inline size_t ntt_lds_bytes(int log_b, int log_c) { return ntt_tile_words((size_t)1 << (log_b + log_c), log_b > 0 ? (size_t)1 << (log_b - 1) : 1) * 4; }
 // one workgroup per CU (tile > 80 KiB of LDS) => 512 threads so that every SIMD still holds 2 waves
 static inline unsigned ntt_threads(size_t lds) { return lds > 80 * 1024 ? 512u : 256u; }
 // tile elements E = B*C: 2^11 by default (64 KiB + twiddles => 2 workgroups per CU); option "ntt_log_tile" overrides for tuning
@@ -93,27 +100,28 @@ static inline int ntt_minw(const stark_ctx* ctx) { return ctx->opt_ntt_min_waves
 // total_log: log2 of all elements the launch covers; small launches take smaller tiles so that the grid still fills the chip
 static inline int pick_log_c(const stark_ctx* ctx, int log_b, int cap, int total_log = 30) {
     int le = ctx->opt_ntt_log_tile; if (!ctx->opt_ntt_log_tile_forced && total_log - le < 9) le = std::max(8, std::min(le, total_log - 8));
-    int lc = std::max(2, le - log_b); return std::max(0, std::min(lc, cap));
+    int lc = std::max(2, le - log_b); lc = std::max(0, std::min(lc, cap));
+    while (lc > 0 && ntt_lds_bytes(log_b, lc) > kMaxLds) --lc;      // 2^10-point sub-NTTs: two columns per tile (36 B per element in LDS)
+    return lc;
 }
 
-template <class F>
-static int32_t launch_strided(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, const fr_t* src, fr_t* dst) {
+template <class F, int MINW, bool STRIDED>
+static void launch_pass(bool pre, unsigned th, size_t lds, hipStream_t st, const NttPassArgs& A, const fr_t* src, fr_t* dst) {
+    const dim3 grid(A.ntiles), block(th);
+    if (STRIDED) { if (pre) hipLaunchKernelGGL((k_ntt_strided<F, MINW, true>), grid, block, lds, st, A, src, dst); else hipLaunchKernelGGL((k_ntt_strided<F, MINW, false>), grid, block, lds, st, A, src, dst); }
+    else { if (pre) hipLaunchKernelGGL((k_ntt_last<F, MINW, true>), grid, block, lds, st, A, src, dst); else hipLaunchKernelGGL((k_ntt_last<F, MINW, false>), grid, block, lds, st, A, src, dst); }
+}
+template <class F, bool STRIDED>
+static int32_t launch_any(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, bool pre, const fr_t* src, fr_t* dst) {
     size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
     if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
-    uint64_t tiles = total_elems >> (A.log_b + A.log_c);
-    if (ntt_minw(ctx) > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_strided<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
-    else hipLaunchKernelGGL((k_ntt_strided<F, 2>), dim3((unsigned)tiles), dim3(ntt_threads(lds)), lds, ctx->stream, A, src, dst);
+    A.ntiles = (uint32_t)(total_elems >> (A.log_b + A.log_c));
+    if (ntt_minw(ctx) > 2 && lds <= 40 * 1024) launch_pass<F, 4, STRIDED>(pre, 256u, lds, ctx->stream, A, src, dst);
+    else launch_pass<F, 2, STRIDED>(pre, ntt_threads(lds), lds, ctx->stream, A, src, dst);
     STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
 }
-template <class F>
-static int32_t launch_last(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, const fr_t* src, fr_t* dst) {
-    size_t lds = ntt_lds_bytes(A.log_b, A.log_c);
-    if (lds > kMaxLds) return ctx->fail(STARK_ERR_UNSUPPORTED, "NTT tile exceeds LDS");
-    uint64_t tiles = total_elems >> (A.log_b + A.log_c);
-    if (ntt_minw(ctx) > 2 && lds <= 40 * 1024) hipLaunchKernelGGL((k_ntt_last<F, 4>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, A, src, dst);
-    else hipLaunchKernelGGL((k_ntt_last<F, 2>), dim3((unsigned)tiles), dim3(ntt_threads(lds)), lds, ctx->stream, A, src, dst);
-    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
-}
+template <class F> static int32_t launch_strided(stark_ctx* ctx, const NttPassArgs& A, uint64_t total_elems, const fr_t* src, fr_t* dst) { return launch_any<F, true>(ctx, A, total_elems, A.pre_direct || A.pre.lo, src, dst); }
+template <class F> static int32_t launch_last(stark_ctx* ctx, const NttPassArgs& A, uint64_t total_elems, const fr_t* src, fr_t* dst) { return launch_any<F, false>(ctx, A, total_elems, A.pre.lo != nullptr, src, dst); }
 
 // `batch` vectors of 2^log_n elements each, contiguous.  data is transformed in place (scratch from the context).
 template <class F>
@@ -129,8 +137,8 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     if (coset) {
         if (!p->have_coset || !fr_eq(p->coset, *coset)) {
             int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
-            if (!inverse) STARK_TRY(fill_table<F>(ctx, *coset, fr_one<F>(), lo_bits, hi_bits, p->coset_tab));                       // g^j
-            else STARK_TRY(fill_table<F>(ctx, fr_inv<F>(*coset), fr_inv<F>(fr_from_u64<F>(1ull << log_n)), lo_bits, hi_bits, p->coset_tab));   // n^-1 g^-k
+            if (!inverse) STARK_TRY(fill_table<F>(ctx, *coset, x32<F>(fr_one<F>()), lo_bits, hi_bits, p->coset_tab));              // g^j
+            else STARK_TRY(fill_table<F>(ctx, fr_inv<F>(*coset), x32<F>(fr_inv<F>(fr_from_u64<F>(1ull << log_n))), lo_bits, hi_bits, p->coset_tab));   // n^-1 g^-k
             p->coset = *coset; p->have_coset = true;
             if (p->coset_direct) { (void)hipFree(p->coset_direct); p->coset_direct = nullptr; }
             if (!inverse && ntt_direct_max(ctx) >= log_n && hipMalloc((void**)&p->coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess)
@@ -143,7 +151,7 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
     const uint64_t total = batch << log_n;
     fr_t* scratch = nullptr;
     if (p->P > 1) { void* s = nullptr; STARK_TRY(ctx_scratch(ctx, total * sizeof(fr_t), &s)); scratch = (fr_t*)s; }
-    NttPassArgs A; memset(&A, 0, sizeof(A));
+    NttPassArgs A; memset(&A, 0, sizeof(A)); pass_consts<F>(A);
     A.log_n = log_n; A.root = p->root.view(); A.pre = none; A.post = none; A.scale = nullptr; A.rest0 = 0; A.log_vec = log_n;
     const fr_t* src = data;
     int rem = log_n;                       // log2 of the current sub-problem size
@@ -183,12 +191,13 @@ void stark::ntt_plans_free(stark_ctx* ctx) { for (auto& kv : ctx->plans) delete 
 
 // Per-DEVICE kernel attributes (the default tile is 64 KiB + twiddles, above the 64 KiB a kernel may use without opting in):
 // called from stark_ctx_create with the context's device current, so a process holding contexts on several GPUs sets them on each.
-void stark::ntt_set_attrs() {
-    (void)hipFuncSetAttribute((const void*)k_ntt_strided<PallasFr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_ntt_last<PallasFr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_ntt_strided<Bls12381Fr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    (void)hipFuncSetAttribute((const void*)k_ntt_last<Bls12381Fr, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+template <class F> static void set_attrs_for() {
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided<F, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_strided<F, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_last<F, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_ntt_last<F, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
 }
+void stark::ntt_set_attrs() { set_attrs_for<PallasFr>(); set_attrs_for<Bls12381Fr>(); }
 
 // Multi-GPU phase A: column NTTs of size 2^log_rows over a row-major [2^log_rows][ncols] slab whose first
 // column has global index col0, followed by the twiddle w_N^(col_global * k), N = 2^log_n.  In place.
@@ -198,7 +207,7 @@ static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t nc
     if (ncols == 0 || (ncols & (ncols - 1))) return ctx->fail(STARK_ERR_INVALID_ARG, "ncols must be a power of two");
     NttPlan* big = nullptr; STARK_TRY(get_plan<F>(ctx, log_n, inverse, &big));        // root table of w_N
     NttPlan* sm = nullptr; STARK_TRY(get_plan<F>(ctx, log_rows, inverse, &sm));       // stage twiddles of w_R (P == 1 plan)
-    NttPassArgs A; memset(&A, 0, sizeof(A));
+    NttPassArgs A; memset(&A, 0, sizeof(A)); pass_consts<F>(A);
     int log_cols = 0; while ((1ull << log_cols) < ncols) ++log_cols;
     A.log_b = log_rows; A.log_c = pick_log_c(ctx, log_rows, log_cols); A.log_n = log_n; A.stride = ncols; A.log_m = log_n;
     A.stage_tw = sm->stage_tw[0]; A.root = big->root.view(); A.rest0 = col0;
@@ -211,7 +220,7 @@ static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t nc
             if (big->shift_tabs.size() >= 32) { STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); auto& old = big->shift_tabs.front(); (void)hipFree(old.second.lo); (void)hipFree(old.second.hi); big->shift_tabs.erase(big->shift_tabs.begin()); }
             big->shift_tabs.push_back({*shift, DevTable()});
             const int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
-            STARK_TRY(fill_table<F>(ctx, *shift, fr_one<F>(), lo_bits, hi_bits, big->shift_tabs.back().second));
+            STARK_TRY(fill_table<F>(ctx, *shift, x32<F>(fr_one<F>()), lo_bits, hi_bits, big->shift_tabs.back().second));
             T = &big->shift_tabs.back().second;
         }
         A.pre = T->view(); A.pre_row_stride = 1ull << (log_n - log_rows);
@@ -291,9 +300,12 @@ int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, s
     if (!ctx || !slab) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
     DevBuf sc; fr_t one_f;
-    if (scale4) { fr_t s = load_fr(scale4); STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &s, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    if (field_id != STARK_FIELD_PALLAS_FR && field_id != STARK_FIELD_BLS12_381_FR) return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+    const bool pallas = field_id == STARK_FIELD_PALLAS_FR;
+    if (scale4) { fr_t s = load_fr(scale4); s = pallas ? x32<PallasFr>(s) : x32<Bls12381Fr>(s);      // into the kernels' table domain
+        STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &s, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
     else if (inverse) {   // suppress the plan's per-row n^-1: multiply by one
-        one_f = field_id == STARK_FIELD_PALLAS_FR ? fr_one<PallasFr>() : fr_one<Bls12381Fr>();
+        one_f = pallas ? x32<PallasFr>(fr_one<PallasFr>()) : x32<Bls12381Fr>(fr_one<Bls12381Fr>());
         STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &one_f, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     int32_t rc;

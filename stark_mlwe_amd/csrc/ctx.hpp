@@ -29,6 +29,7 @@ struct stark_params {
 struct stark_comm;
 struct stark_ctx {
     int device = 0;
+    int num_cus = 256;                               // compute units of the device (persistent NTT grids)
     stark_comm* comm = nullptr;                      // RCCL communicator spanning the ranks (capi_comm.hip); nullptr until stark_comm_init
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -173,6 +173,77 @@ template <class F> FR_HD fr_t fr_pow5_r29(const fr_t& x) {
     return fr29_pack_reduce<F>(x5.l);
 }
 
+// ---- lazily reduced nine-limb values (NTT butterflies, ntt_dev.hpp) ----------------------------------------------
+// Between two Montgomery steps a value may be any non-negative integer below 2^261 whose limbs 0..7 stay below
+// 7 * 2^29 (limb 8 absorbs what is above 2^232).  fr29_mul_mont(tw, b) accepts b with limbs up to 6 * 2^29
+// (9 * 2^29 * 6 * 2^29 + the reduction's 8 * 2^58 stays below 2^64 per column) and returns limbs below 2^29 and a
+// value below (V_b * r / 2^261 + 1) r, i.e. below 1.6 r for V_b <= 41 in both fields.
+FR_HD void fr29_norm(fr29_t& a) {               // carry pass: limbs 0..7 back below 2^29, the value unchanged
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a.l[i + 1] += a.l[i] >> 29; a.l[i] &= FR_M29; }
+}
+// Cheap reduction of a lazy value WITHOUT a product: carry pass, q = floor(top / (r_8 + 1)) by a magic multiply (exact for
+// top < 2^29), x <- x - q r with signed carries.  q never exceeds x / r, and what is left is below (r_8 + q + 1) 2^232, i.e.
+// below 1.00002 r: limbs below 2^29, the same residue.  (~45 simple instructions against 81 + 36 MACs and a column walk.)
+template <class F> FR_HD void fr29_partial_reduce(fr29_t& x) {
+    constexpr uint64_t d = (uint64_t)fr_p29<F>(8) + 1, magic = ((1ull << 52) + d - 1) / d;     // ceil(2^52 / d) < 2^31
+    fr29_norm(x);
+    const uint32_t q = (uint32_t)(((uint64_t)x.l[8] * magic) >> 52);
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int64_t t = (int64_t)x.l[i] + carry - (int64_t)((uint64_t)q * fr_p29<F>(i));
+        if (i < 8) { x.l[i] = (uint32_t)t & FR_M29; carry = t >> 29; } else x.l[8] = (uint32_t)t;
+    }
+}
+// One radix-2 decimation-in-time butterfly  (a, b) <- (a + tw*b, a - tw*b)  on lazily reduced values.
+// D = 4r written with every limb below the top lifted by 2^29 (and the matching borrow taken from the limb above),
+// so that  a + D - p  never borrows limb-wise: p has limbs below 2^29 and a top limb below 1.6 * r_8 < D_8.
+// Growth per stage: limbs of a by at most 2^29 (sum) / 2^30 (difference), the value by at most 4r.
+template <class F> FR_HD void ntt29_butterfly(fr29_t& a, fr29_t& b, const fr29_t& tw, const uint32_t* __restrict__ D, bool norm) {
+    if (norm) { fr29_norm(a); fr29_norm(b); }
+    const fr29_t p = fr29_mul_mont<F>(tw, b);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const uint32_t av = a.l[k]; a.l[k] = av + p.l[k]; b.l[k] = av + D[k] - p.l[k]; }
+}
+// The same with the twiddle 1: no product.  FRESH: b is a canonical input (limbs below 2^29, below r) and is taken as it is;
+// otherwise b is first brought back below 1.00002 r — an unmultiplied operand would double the value at every stage.
+template <class F, bool FRESH> FR_HD void ntt29_butterfly_w1(fr29_t& a, fr29_t& b, const uint32_t* __restrict__ D) {
+    if (!FRESH) fr29_partial_reduce<F>(b);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const uint32_t av = a.l[k], bv = b.l[k]; a.l[k] = av + bv; b.l[k] = av + D[k] - bv; }
+}
+// The first HEAD (<= 3) stages of a group of 2^HEAD consecutive rows, in registers: their twiddles have compile-time
+// positions, so the trivial ones (all of stage 1, half of stage 2, a quarter of stage 3) cost no product:
+// 5 products per 8 points instead of 12.  w1 = w_8, w2 = w_4, w3 = w_8^3 in the tables' domain.
+template <class F, int HEAD> FR_HD void ntt29_head(fr29_t (&x)[1 << HEAD], const fr29_t& w1, const fr29_t& w2, const fr29_t& w3, const uint32_t* __restrict__ D) {
+#pragma unroll
+    for (int g = 0; g < (1 << (HEAD - 1)); ++g) ntt29_butterfly_w1<F, true>(x[2 * g], x[2 * g + 1], D);
+    if constexpr (HEAD >= 2) {
+#pragma unroll
+        for (int g = 0; g < (1 << (HEAD - 2)); ++g) {
+            ntt29_butterfly_w1<F, false>(x[4 * g], x[4 * g + 2], D);
+            ntt29_butterfly<F>(x[4 * g + 1], x[4 * g + 3], w2, D, false);
+        }
+    }
+    if constexpr (HEAD == 3) {
+        ntt29_butterfly_w1<F, false>(x[0], x[4], D);
+        ntt29_butterfly<F>(x[1], x[5], w1, D, false);
+        ntt29_butterfly<F>(x[2], x[6], w2, D, false);
+        ntt29_butterfly<F>(x[3], x[7], w3, D, false);
+    }
+}
+// Stage s (1-based) of a tile starts from limbs below (1 + 2*(stages since the last carry pass)) * 2^29: a carry pass
+// on both inputs before stages 4, 7, 10 keeps the multiplied operand at <= 5 * 2^29 and every sum below 2^32.
+FR_HD bool ntt29_norm_before(int s) { return s > 1 && (s - 1) % 3 == 0; }
+FR_HD bool ntt29_norm_after(int stages) { return stages >= 1 && (stages - 1) % 3 == 2; }   // limbs reach 7 * 2^29 after stages 3, 6, 9
+// host: the constants of the lazy butterflies
+template <class F> inline void ntt29_offset(uint32_t D[9]) {
+    uint64_t cy = 0; uint32_t c[9];
+    for (int i = 0; i < 9; ++i) { const uint64_t v = (uint64_t)fr_p29<F>(i) * 4 + cy; c[i] = i < 8 ? (uint32_t)(v & FR_M29) : (uint32_t)v; cy = v >> 29; }
+    for (int i = 0; i < 9; ++i) D[i] = c[i] + (i < 8 ? (1u << 29) : 0u) - (i > 0 ? 1u : 0u);
+}
+
 // Host side: the nine limbs of c * R' mod r for a constant given in the R domain (c * R mod r).
 template <class F> inline void fr29_const_from(const fr_t& c_R, uint32_t out[9]) {
     const fr_t c32 = fr_mul_portable<F>(c_R, fr_from_u64<F>(32));   // (cR)(32R)/R = 32 c R = c R'

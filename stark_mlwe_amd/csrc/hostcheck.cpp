@@ -55,6 +55,63 @@ int hc_wide_dot32(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out)
     for (size_t i = 0; i < n; ++i) fr_wide_mac_f<PF>(w, ld4(a + 4 * i), ld4(b + 4 * i));
     st4(out, fr_wide_reduce<PF>(w)); return 0;
 }
+}  // extern "C"
+// One size-2^log_b sub-NTT exactly as a tile of ntt_dev.hpp computes it (nine-limb lazy decimation-in-time butterflies, the same carry-pass
+// schedule, tables carrying the factor 32, the multiply-by-32 epilogue), sequentially on the host.  data: 2^log_b canonical Montgomery values,
+// natural order in and out.  Also reports the largest limb / top limb any operand of a product reached (bounds check for the tests).
+template <class F> static int hc_ntt29_impl(uint64_t* data, int log_b, int inverse, uint64_t* max_limb, uint64_t* max_top) {
+    if (log_b < 1 || log_b > 16) return -1;
+    const size_t B = (size_t)1 << log_b;
+    fr_t w = fr_root_of_unity<F>((unsigned)log_b); if (inverse) w = fr_inv<F>(w);
+    const fr_t k32 = fr_from_u64<F>(32);
+    std::vector<fr29_t> tw(B / 2), x(B);
+    { fr_t acc = k32; for (size_t i = 0; i < B / 2; ++i) { tw[i] = fr29_unpack(acc); acc = fr_mul<F>(acc, w); } }
+    uint32_t D[9]; ntt29_offset<F>(D);
+    auto brev = [&](size_t v) { size_t r = 0; for (int i = 0; i < log_b; ++i) r |= ((v >> i) & 1) << (log_b - 1 - i); return r; };
+    for (size_t p = 0; p < B; ++p) x[brev(p)] = fr29_unpack(ld4(data + 4 * p));
+    uint64_t ml = 0, mt = 0;
+    const int head = log_b >= 3 ? 3 : log_b;
+    {   // the register head of the kernels: groups of 2^head consecutive (bit-reversed) rows
+        const fr29_t w1 = tw[log_b >= 3 ? B >> 3 : 0], w2 = tw[log_b >= 2 ? B >> 2 : 0], w3 = tw[log_b >= 3 ? 3 * (B >> 3) : 0];
+        for (size_t g = 0; g < (B >> head); ++g) {
+            fr29_t* xs = &x[g << head];
+            if (head == 3) ntt29_head<F, 3>(*reinterpret_cast<fr29_t (*)[8]>(xs), w1, w2, w3, D);
+            else if (head == 2) ntt29_head<F, 2>(*reinterpret_cast<fr29_t (*)[4]>(xs), w1, w2, w3, D);
+            else ntt29_head<F, 1>(*reinterpret_cast<fr29_t (*)[2]>(xs), w1, w2, w3, D);
+        }
+    }
+    for (int s = head + 1; s <= log_b; ++s) {
+        const size_t half = (size_t)1 << (s - 1); const bool nrm = ntt29_norm_before(s);
+        for (size_t bq = 0; bq < B / 2; ++bq) {
+            const size_t j = bq & (half - 1), grp = bq >> (s - 1), i0 = (grp << s) + j, i1 = i0 + half;
+            fr29_t a = x[i0], b = x[i1];
+            { fr29_t bb = b, aa = a; if (nrm) { fr29_norm(bb); fr29_norm(aa); } for (int k = 0; k < 8; ++k) { ml = std::max<uint64_t>(ml, bb.l[k]); ml = std::max<uint64_t>(ml, aa.l[k]); } mt = std::max<uint64_t>(mt, std::max(bb.l[8], aa.l[8])); }
+            ntt29_butterfly<F>(a, b, tw[j << (log_b - s)], D, nrm);
+            x[i0] = a; x[i1] = b;
+        }
+    }
+    const bool nrm_out = ntt29_norm_after(log_b);
+    fr_t mult = k32; if (inverse) mult = fr_mul<F>(k32, fr_inv<F>(fr_from_u64<F>((uint64_t)B)));
+    for (size_t k = 0; k < B; ++k) {
+        fr29_t y = x[k];
+        for (int i = 0; i < 8; ++i) ml = std::max<uint64_t>(ml, nrm_out ? 0 : y.l[i]);
+        if (inverse) {   // an output with a table factor: the product is the reduction
+            if (nrm_out) fr29_norm(y);
+            mt = std::max<uint64_t>(mt, y.l[8]);
+            const fr29_t r = fr29_mul_mont<F>(fr29_unpack(mult), y);
+            st4(data + 4 * k, fr29_pack_reduce<F>(r.l));
+        } else {         // no factor: reduce without a product
+            fr29_partial_reduce<F>(y);
+            st4(data + 4 * k, fr29_pack_reduce<F>(y.l));
+        }
+    }
+    if (max_limb) *max_limb = ml; if (max_top) *max_top = mt;
+    return 0;
+}
+extern "C" {
+int hc_ntt29(int field, uint64_t* data, int log_b, int inverse, uint64_t* max_limb, uint64_t* max_top) {
+    return field == 0 ? hc_ntt29_impl<PallasFr>(data, log_b, inverse, max_limb, max_top) : hc_ntt29_impl<Bls12381Fr>(data, log_b, inverse, max_limb, max_top);
+}
 int hc_blake3(const uint8_t* p, size_t n, uint8_t* out32) { host::Blake3::hash(p, n, out32); return 0; }
 int hc_chacha12_u64s(const uint8_t* seed32, size_t n, uint64_t* out) { host::ChaCha12Rng r(seed32); for (size_t i = 0; i < n; ++i) out[i] = r.next_u64(); return 0; }
 int hc_from_le_bytes_mod_order(const uint8_t* b, size_t n, uint64_t* out) { st4(out, host::h_from_le_bytes_mod_order(b, n)); return 0; }

@@ -11,12 +11,20 @@
 //                   inter-pass twiddle w_m^(rest*k) on the way out.  In place.
 //   last pass     : contiguous size-B sub-NTTs, C rows per tile chosen so that the digit-reversed
 //                   (transposing) store writes C adjacent elements.
-// Inside a tile: decimation-in-frequency butterflies in LDS ([element][half] 16-B slots => conflict-free
-// ds_read/write_b128), stage twiddles w_B^e staged in LDS once per workgroup; the bit-reversed
-// result order is undone by the LDS read address of the store phase.
+// Inside a tile the elements live in LDS as NINE 29-BIT LIMBS, lazily reduced (fr29.hpp): decimation-in-time butterflies
+// (a, b) <- (a + w b, a - w b + 4r), one carry-free 81-MAC product and one Montgomery step by 2^261 per butterfly, sums and
+// differences limb-wise without carries, a carry pass every third stage.  In DIT every stage multiplies one operand, so values
+// grow linearly (<= 4r per stage, 41 r over ten stages, inside the 2^261 / r = 128 (Pallas) / 70 (BLS12-381) head-room of nine
+// limbs); decimation in frequency would double the unmultiplied sum every stage.  Against the eight-word exact form (8x8 MACs
+// with a carry add each, conditional subtractions in every add/sub) a butterfly costs 995 instead of 1 420-1 530 SIMD cycles
+// (tools/bf_bench.hip).  Points are stored bit-reversed on load, results leave in natural order; the last stage is fused with
+// the pass epilogue (inter-pass twiddle / coset post-scale / n^-1), which is also the product that brings the value back
+// below 2r for the canonical eight-word store.  Every table the kernels read (stage twiddles, inter-pass twiddles, coset
+// powers, scales) carries the factor 32 = 2^261 / 2^256, so that one Montgomery step IS the product in the 2^256 domain.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fr.hpp"
+#include "fr29.hpp"
 #include "dev_common.hpp"
 
 namespace stark {
@@ -49,161 +57,218 @@ struct NttPassArgs {
     const fr_t* pre_direct;  // first pass: g^j at index j; nullptr => `pre` lookup
     uint32_t nz_points;      // first pass of a zero-padded transform (LDE): only the points p < nz_points of every sub-NTT are non-zero
                              // in memory; the rest is taken as zero without being read (0 = all points are read)
+    uint32_t dlimb[9];       // 4r in borrow-proof nine-limb form (fr29.hpp ntt29_offset)
+    uint32_t ntiles;         // tiles of the launch (a workgroup walks tiles blockIdx.x, + gridDim.x, ...)
     uint64_t pre_row_stride; // != 0 (multi-GPU column slabs): the pre-scale exponent of tile element (p, column) is the GLOBAL natural index
                              // p * pre_row_stride + rest0 + column, not the position inside the local slab
 };
 
-__device__ __forceinline__ fr_t lds_ld(const uint4* lo, const uint4* hi, int slot) {
-    uint4 a = lo[slot], b = hi[slot];
-    fr_t x; x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w; x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w; return x;
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave
+// (s_waitcnt vmcnt(0)), which would turn the prefetch of the next tile into a blocking load at the first stage barrier.  The pass
+// kernels exchange data between threads through LDS alone (a thread's global loads and stores touch elements no other thread of
+// the launch touches), so the LDS counter is the only one the barrier has to drain.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the tile in LDS: nine 29-bit limbs per element, SoA over the slot index (two 16-byte halves + the top limb) ----
+struct Tile29 { uint4* lo; uint4* mid; uint32_t* top; };
+__device__ __forceinline__ fr29_t t29_ld(const Tile29& T, int slot) {
+    const uint4 a = T.lo[slot], b = T.mid[slot]; fr29_t x;
+    x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w; x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w; x.l[8] = T.top[slot]; return x;
 }
-__device__ __forceinline__ void lds_st(uint4* lo, uint4* hi, int slot, const fr_t& x) {
-    lo[slot] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]); hi[slot] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+__device__ __forceinline__ void t29_st(const Tile29& T, int slot, const fr29_t& x) {
+    T.lo[slot] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]); T.mid[slot] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]); T.top[slot] = x.l[8];
 }
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return bits == 0 ? 0u : (__brev(x) >> (32 - bits)); }
-
-// All log_b DIF stages over the tile in LDS; slot(p, c) = p*C + c.  Output X[bitrev(p)] lands at p.
+// LDS words of a tile with E elements and NT stage twiddles (both SoA blocks 16-byte aligned)
+__host__ __device__ constexpr size_t ntt_tile_words(size_t E, size_t NT) { return ((9 * E + 3) & ~(size_t)3) + ((9 * NT + 3) & ~(size_t)3); }
+struct TileLds { Tile29 data, tw; };
+__device__ __forceinline__ TileLds tile_lds(uint4* lds, int E, int NT) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* t = w + ((9 * (size_t)E + 3) & ~(size_t)3);
+    return TileLds{Tile29{lds, lds + E, w + 8 * (size_t)E}, Tile29{reinterpret_cast<uint4*>(t), reinterpret_cast<uint4*>(t) + NT, t + 8 * (size_t)NT}};
+}
 template <class F>
-__device__ __forceinline__ void lds_dif(uint4* dlo, uint4* dhi, const uint4* tlo, const uint4* thi, int log_b, int log_c, int nstages) {
-    const int B = 1 << log_b, C = 1 << log_c, nbf = (B >> 1) << log_c;
-    for (int s = 0; s < nstages; ++s) {
-        const int log_half = log_b - 1 - s, half = 1 << log_half;
+__device__ __forceinline__ void load_stage_tw(const Tile29& T, const fr_t* tw, int nt) {
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) t29_st(T, i, fr29_unpack(ldg(tw + i)));
+}
+// The first HEAD = min(3, log_b) stages in registers (fr29.hpp ntt29_head), straight from the global loads: a thread takes the
+// 2^HEAD points u + (B/2^HEAD) t of one column — in bit-reversed placement they are the consecutive rows (bitrev(u) << HEAD) + bitrev(t)
+// — and stores the group into LDS.  `load(p, c)` delivers point p of tile column c as a lazy nine-limb value.
+template <class F, int HEAD, class Load>
+__device__ __forceinline__ void head_to_lds(const NttPassArgs& A, const Tile29& D, bool c_fastest, Load load) {
+    constexpr int NP = 1 << HEAD;
+    const int B = 1 << A.log_b, C = 1 << A.log_c, nu = B >> HEAD, ngrp = nu << A.log_c;
+    fr29_t w1, w2, w3; w1 = w2 = w3 = fr29_unpack(ldg(A.stage_tw));
+    if (HEAD >= 2) w2 = fr29_unpack(ldg(A.stage_tw + (B >> 2)));
+    if (HEAD == 3) { w1 = fr29_unpack(ldg(A.stage_tw + (B >> 3))); w3 = fr29_unpack(ldg(A.stage_tw + 3 * (B >> 3))); }
+    for (int idx = threadIdx.x; idx < ngrp; idx += blockDim.x) {
+        int c, u;
+        if (c_fastest) { c = idx & (C - 1); u = idx >> A.log_c; } else { u = idx & (nu - 1); c = idx >> (A.log_b - HEAD); }
+        fr29_t x[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) x[k] = load(u + nu * (int)(__brev((uint32_t)k) >> (32 - HEAD)), c);
+        ntt29_head<F, HEAD>(x, w1, w2, w3, A.dlimb);
+        const int row0 = (int)(bitrev((uint32_t)u, A.log_b - HEAD) << HEAD);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) t29_st(D, ((row0 + k) << A.log_c) + c, x[k]);
+    }
+}
+template <class F, class Load>
+__device__ __forceinline__ int head_dispatch(const NttPassArgs& A, const Tile29& D, bool c_fastest, Load load) {
+    if (A.log_b >= 3) { head_to_lds<F, 3>(A, D, c_fastest, load); return 3; }
+    if (A.log_b == 2) { head_to_lds<F, 2>(A, D, c_fastest, load); return 2; }
+    head_to_lds<F, 1>(A, D, c_fastest, load); return 1;
+}
+// Stages head+1 .. log_b-1 of the decimation-in-time sub-NTTs of a tile, in LDS.  slot(row, c) = row*C + c; the points sit at
+// bit-reversed rows, the outputs come out in natural order.  Stage s pairs rows j and j + 2^(s-1) of every group of 2^s rows
+// with the twiddle w_(2^s)^j = w_B^(j * B / 2^s).  (The trivial twiddles j == 0 of these stages — one row in 8, 16, ... — are
+// multiplied like the others: a branch on j would diverge inside a wave.)
+template <class F>
+__device__ __forceinline__ void lds_dit(const NttPassArgs& A, const Tile29& D, const Tile29& T, int head) {
+    const int C = 1 << A.log_c, nbf = ((1 << A.log_b) >> 1) << A.log_c;
+#pragma unroll 1
+    for (int s = head + 1; s < A.log_b; ++s) {
+        const int lh = s - 1, half = 1 << lh; const bool nrm = ntt29_norm_before(s);
+#pragma unroll 1
         for (int q = threadIdx.x; q < nbf; q += blockDim.x) {
-            const int c = q & (C - 1), bq = q >> log_c;
-            const int pos = bq & (half - 1), grp = bq >> log_half;
-            const int i0 = ((grp << (log_half + 1)) + pos) * C + c, i1 = i0 + half * C;
-            fr_t a = lds_ld(dlo, dhi, i0), b = lds_ld(dlo, dhi, i1);
-            fr_t sum = fr_add<F>(a, b), dif = fr_sub<F>(a, b);
-            if (pos != 0) dif = fr_mul<F>(dif, lds_ld(tlo, thi, pos << s));   // w_B^(pos*2^s); pos == 0 => 1
-            lds_st(dlo, dhi, i0, sum); lds_st(dlo, dhi, i1, dif);
+            const int c = q & (C - 1), bq = q >> A.log_c, j = bq & (half - 1), grp = bq >> lh;
+            const int i0 = (((grp << s) + j) << A.log_c) + c, i1 = i0 + (half << A.log_c);
+            fr29_t a = t29_ld(D, i0), b = t29_ld(D, i1);
+            ntt29_butterfly<F>(a, b, t29_ld(T, j << (A.log_b - s)), A.dlimb, nrm);
+            t29_st(D, i0, a); t29_st(D, i1, b);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
-// The last TAIL (<= 3) DIF stages of one column block, in registers: x[0..2^TAIL) are consecutive points of
-// the block.  Their twiddles w_(2h)^pos have compile-time positions, so the trivial ones (pos == 0: all of
-// the last stage, half of the one before, ...) cost nothing: 5 products per 8 points instead of 12.
-template <class F, int TAIL>
-__device__ __forceinline__ void dif_tail(fr_t* x, const fr_t& w1, const fr_t& w2, const fr_t& w3) {   // w_k = w_8^k (TAIL == 3); w2 = w_4 (TAIL == 2)
-    if (TAIL == 3) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            fr_t a = x[p], b = x[p + 4]; x[p] = fr_add<F>(a, b); fr_t d = fr_sub<F>(a, b);
-            x[p + 4] = p == 0 ? d : fr_mul<F>(d, p == 1 ? w1 : (p == 2 ? w2 : w3));
+// The last stage (when the head left one) fused with the pass epilogue: emit(k, c, y, norm_out) receives output k of column c.
+template <class F, class Emit>
+__device__ __forceinline__ void last_stage(const NttPassArgs& A, const Tile29& D, const Tile29& T, int head, Emit emit) {
+    const int B = 1 << A.log_b, C = 1 << A.log_c;
+    const bool nrm_out = ntt29_norm_after(A.log_b);
+    if (A.log_b > head) {
+        const int nbf = (B >> 1) << A.log_c; const bool nrm = ntt29_norm_before(A.log_b);
+#pragma unroll 1
+        for (int q = threadIdx.x; q < nbf; q += blockDim.x) {
+            const int c = q & (C - 1), j = q >> A.log_c;
+            fr29_t a = t29_ld(D, (j << A.log_c) + c), b = t29_ld(D, ((j + (B >> 1)) << A.log_c) + c);
+            ntt29_butterfly<F>(a, b, t29_ld(T, j), A.dlimb, nrm);
+            emit((uint32_t)j, c, a, nrm_out); emit((uint32_t)(j + (B >> 1)), c, b, nrm_out);
         }
+    } else {
+        for (int q = threadIdx.x; q < (B << A.log_c); q += blockDim.x) { const int c = q & (C - 1), k = q >> A.log_c; emit((uint32_t)k, c, t29_ld(D, q), nrm_out); }
     }
-    if (TAIL >= 2) {
-#pragma unroll
-        for (int g = 0; g < (TAIL >= 2 ? (1 << (TAIL - 2)) : 0); ++g)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                fr_t a = x[4 * g + p], b = x[4 * g + p + 2]; x[4 * g + p] = fr_add<F>(a, b); fr_t d = fr_sub<F>(a, b);
-                x[4 * g + p + 2] = p == 0 ? d : fr_mul<F>(d, w2);
-            }
-    }
-#pragma unroll
-    for (int g = 0; g < (1 << (TAIL - 1)); ++g) { fr_t a = x[2 * g], b = x[2 * g + 1]; x[2 * g] = fr_add<F>(a, b); x[2 * g + 1] = fr_sub<F>(a, b); }
 }
-
+// y * mult -> canonical eight-word value.  mult comes from a table in the kernels' domain (entries carry the factor 32 that
+// turns the Montgomery step by 2^261 into a product in the 2^256 domain), y is lazily reduced.
 template <class F>
-__device__ __forceinline__ void load_stage_tw(uint4* tlo, uint4* thi, const fr_t* tw, int log_b) {
-    const int nt = (1 << log_b) >> 1;
-    for (int i = threadIdx.x; i < nt; i += blockDim.x) lds_st(tlo, thi, i, ldg(tw + i));
+__device__ __forceinline__ fr_t finish29(fr29_t y, const fr_t& mult, bool norm) {
+    if (norm) fr29_norm(y);
+    const fr29_t r = fr29_mul_mont<F>(fr29_unpack(mult), y);
+    return fr29_pack_reduce<F>(r.l);
 }
+// an output that takes no factor: reduced without a product
+template <class F>
+__device__ __forceinline__ fr_t finish29_plain(fr29_t y) { fr29_partial_reduce<F>(y); return fr29_pack_reduce<F>(y.l); }
 
-// Last TAIL stages of every (column, block) of the tile in registers, then the pass epilogue straight from
-// the registers: STRIDED: inter-pass twiddle w_m^(rest*k) and in-place store; else the digit-reversing
-// store of the last pass (optional post-scale).
-template <class F, int TAIL, bool STRIDED>
-__device__ __forceinline__ void tail_store(const NttPassArgs& A, const uint4* dlo, const uint4* dhi, const uint4* tlo, const uint4* thi,
-                                           fr_t* dst, uint64_t tile, uint64_t k1_0, uint64_t k2) {
-    constexpr int NP = 1 << TAIL;
-    const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c, nblk = E >> TAIL;
-    fr_t w1 = fr_zero<F>(), w2 = fr_zero<F>(), w3 = fr_zero<F>();
-    if (TAIL == 3) { w1 = lds_ld(tlo, thi, B >> 3); w2 = lds_ld(tlo, thi, B >> 2); w3 = lds_ld(tlo, thi, 3 * (B >> 3)); }
-    else if (TAIL == 2) w2 = lds_ld(tlo, thi, B >> 2);
-    const int sh = A.log_n - A.log_m;                  // w_m = w_N^(2^sh)
-    for (int idx = threadIdx.x; idx < nblk; idx += blockDim.x) {
-        const int c = idx & (C - 1), blk = idx >> A.log_c;
-        fr_t x[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) x[p] = lds_ld(dlo, dhi, (((blk << TAIL) + p) << A.log_c) + c);
-        if (TAIL > 0) dif_tail<F, (TAIL > 0 ? TAIL : 1)>(x, w1, w2, w3);
-        const uint64_t rest = A.rest0 + (tile << A.log_c) + c;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const uint32_t k = bitrev((uint32_t)((blk << TAIL) + p), A.log_b);
-            fr_t y = x[p];
-            if (STRIDED) {
-                const uint64_t e = (rest * k) << sh;
-                if (e) y = fr_mul<F>(y, A.tw_direct ? ldg(A.tw_direct + (uint64_t)k * A.stride + (rest - A.rest0)) : pow_lookup<F>(A.root, e));
-                stg(dst + (uint64_t)k * A.stride + c, y);
-            } else {
-                const uint64_t out = ((uint64_t)k << (A.log_b1 + A.log_b2)) + (k2 << A.log_b1) + k1_0 + c;
-                if (A.post.lo) y = fr_mul<F>(y, pow_lookup<F>(A.post, out));
-                else if (A.scale) y = fr_mul<F>(y, *A.scale);
-                stg(dst + out, y);
-            }
-        }
-    }
-}
-
-// Strided pass.  grid.x = (n / (B*S)) * (S / C) tiles.
-template <class F, int MINW>
+// ---- the pass kernels ------------------------------------------------------------------------------------------------------
+// One workgroup per tile (the loop lets a launch use a smaller grid).  Tried and dropped: persistent workgroups that
+// prefetch the next tile's points into registers underneath the LDS stages — the kernels are bound by VALU issue (SQ counters:
+// the VALU pipe of a SIMD is busy 90-100 % of the time), not by an HBM phase that could be hidden.
+//
+// PRE: the pass applies a coset pre-scale on load (first pass of a coset transform): the scaled points go to LDS first and the head
+// works from there — eight inlined table products would not unroll.
+struct TileJob { uint64_t base, tile; };     // strided: element offset of the tile, tile index inside its outer block
+template <class F, int MINW, bool PRE>
 __global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttPassArgs A, const fr_t* src, fr_t* dst) {
     extern __shared__ uint4 lds[];
-    const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c;
-    uint4 *dlo = lds, *dhi = lds + E, *tlo = lds + 2 * E, *thi = tlo + (B >> 1);
+    const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c, NT = B > 1 ? B >> 1 : 1;
+    const TileLds L = tile_lds(lds, E, NT);
     const uint64_t tiles_per_outer = A.stride >> A.log_c;
-    const uint64_t outer = blockIdx.x / tiles_per_outer, tile = blockIdx.x % tiles_per_outer;
-    const uint64_t base = (outer << A.log_m) + (tile << A.log_c);
-    load_stage_tw<F>(tlo, thi, A.stage_tw, A.log_b);
-    for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
-        const int c = idx & (C - 1), p = idx >> A.log_c;
-        const uint64_t g = base + (uint64_t)p * A.stride + c;
-        if (A.nz_points && (uint32_t)p >= A.nz_points) { lds_st(dlo, dhi, idx, fr_zero<F>()); continue; }
-        fr_t x = ldg(src + g);
-        if (A.pre_direct) x = fr_mul<F>(x, ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1))));
-        else if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, A.pre_row_stride ? (uint64_t)p * A.pre_row_stride + A.rest0 + (tile << A.log_c) + c : g));
-        lds_st(dlo, dhi, idx, x);
+    auto job = [&](uint64_t t) { const uint64_t outer = t / tiles_per_outer, tile = t % tiles_per_outer; return TileJob{(outer << A.log_m) + (tile << A.log_c), tile}; };
+    load_stage_tw<F>(L.tw, A.stage_tw, NT);
+    for (uint64_t t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
+        const TileJob J = job(t);
+        int head;
+        if (PRE) {
+            for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
+                const int c = idx & (C - 1), p = idx >> A.log_c;
+                fr29_t x;
+                if (A.nz_points && (uint32_t)p >= A.nz_points) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) x.l[i] = 0;
+                } else {
+                    const uint64_t g = J.base + (uint64_t)p * A.stride + c;
+                    const fr_t m = A.pre_direct ? ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1)))
+                                                : pow_lookup<F>(A.pre, A.pre_row_stride ? (uint64_t)p * A.pre_row_stride + A.rest0 + (J.tile << A.log_c) + c : g);
+                    x = fr29_mul_mont<F>(fr29_unpack(m), fr29_unpack(ldg(src + g)));
+                }
+                t29_st(L.data, (int)(bitrev((uint32_t)p, A.log_b) << A.log_c) + c, x);
+            }
+            lds_barrier();
+            head = head_dispatch<F>(A, L.data, true, [&](int p, int c) -> fr29_t { return t29_ld(L.data, (int)(bitrev((uint32_t)p, A.log_b) << A.log_c) + c); });
+        } else {
+            head = head_dispatch<F>(A, L.data, true, [&](int p, int c) -> fr29_t {
+                fr29_t x;
+                if (A.nz_points && (uint32_t)p >= A.nz_points) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) x.l[i] = 0;
+                } else x = fr29_unpack(ldg(src + J.base + (uint64_t)p * A.stride + c));
+                return x;
+            });
+        }
+        lds_barrier();
+        lds_dit<F>(A, L.data, L.tw, head);
+        // inter-pass twiddle w_m^(rest*k) and the in-place store
+        const int sh = A.log_n - A.log_m;
+        fr_t* out = dst + J.base;
+        last_stage<F>(A, L.data, L.tw, head, [&](uint32_t k, int c, const fr29_t& y, bool nrm_out) {
+            const uint64_t rest = A.rest0 + (J.tile << A.log_c) + c;
+            const fr_t tw = A.tw_direct ? ldg(A.tw_direct + (uint64_t)k * A.stride + (rest - A.rest0)) : pow_lookup<F>(A.root, (rest * k) << sh);
+            stg(out + (uint64_t)k * A.stride + c, finish29<F>(y, tw, nrm_out));
+        });
+        lds_barrier();                                                   // the tile in LDS is free again
     }
-    __syncthreads();
-    const int tail = A.log_b >= 3 ? 3 : A.log_b;
-    lds_dif<F>(dlo, dhi, tlo, thi, A.log_b, A.log_c, A.log_b - tail);
-    if (tail == 3) tail_store<F, 3, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
-    else if (tail == 2) tail_store<F, 2, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
-    else if (tail == 1) tail_store<F, 1, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
-    else tail_store<F, 0, true>(A, dlo, dhi, tlo, thi, dst + base, tile, 0, 0);
 }
 
-// Last (contiguous) pass with the digit-reversing store.  grid.x = n / (B*C) tiles.
-template <class F, int MINW>
-__global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_last(NttPassArgs A, const fr_t* src, fr_t* dst) {
+// Last (contiguous) pass with the digit-reversing store.  Tiles = n / (B*C).  PRE as above (single-pass coset transforms).
+template <class F, int MINW, bool PRE>
+__global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_last(NttPassArgs A, const fr_t* src0, fr_t* dst0) {
     extern __shared__ uint4 lds[];
-    const int B = 1 << A.log_b, C = 1 << A.log_c, E = B << A.log_c;
-    uint4 *dlo = lds, *dhi = lds + E, *tlo = lds + 2 * E, *thi = tlo + (B >> 1);
-    // tile -> (k2, k1 block): consecutive tiles walk k1 blocks first
+    const int B = 1 << A.log_b, E = B << A.log_c, NT = B > 1 ? B >> 1 : 1;
+    const TileLds L = tile_lds(lds, E, NT);
+    // tile -> (vector, k2, k1 block): consecutive tiles walk k1 blocks first
     const uint64_t k1_blocks = (1ull << A.log_b1) >> A.log_c;                  // >= 1 (C divides B1)
     const uint64_t tiles_per_vec = k1_blocks << A.log_b2;
-    const uint64_t vec = blockIdx.x / tiles_per_vec, vt = blockIdx.x % tiles_per_vec;
-    const uint64_t k2 = vt / k1_blocks, k1_0 = (vt % k1_blocks) << A.log_c;
-    src += vec << A.log_vec; dst += vec << A.log_vec;
-    load_stage_tw<F>(tlo, thi, A.stage_tw, A.log_b);
-    for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
-        const int p = idx & (B - 1), c = idx >> A.log_b;               // p fastest: contiguous reads
-        const uint64_t o = ((k1_0 + c) << A.log_b2) + k2;
-        const uint64_t g = (o << A.log_b) + p;
-        fr_t x = ldg(src + g);
-        if (A.pre.lo) x = fr_mul<F>(x, pow_lookup<F>(A.pre, g));       // only when this is also the first pass
-        lds_st(dlo, dhi, (p << A.log_c) + c, x);
+    load_stage_tw<F>(L.tw, A.stage_tw, NT);
+    for (uint64_t t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
+        const uint64_t vec = t / tiles_per_vec, vt = t % tiles_per_vec, k2 = vt / k1_blocks, k1_0 = (vt % k1_blocks) << A.log_c;
+        const fr_t* src = src0 + (vec << A.log_vec); fr_t* dst = dst0 + (vec << A.log_vec);
+        int head;
+        if (PRE) {
+            for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
+                const int p = idx & (B - 1), c = idx >> A.log_b;               // p fastest: contiguous reads
+                const uint64_t g = ((((k1_0 + c) << A.log_b2) + k2) << A.log_b) + p;
+                t29_st(L.data, (int)(bitrev((uint32_t)p, A.log_b) << A.log_c) + c, fr29_mul_mont<F>(fr29_unpack(pow_lookup<F>(A.pre, g)), fr29_unpack(ldg(src + g))));
+            }
+            lds_barrier();
+            head = head_dispatch<F>(A, L.data, false, [&](int p, int c) -> fr29_t { return t29_ld(L.data, (int)(bitrev((uint32_t)p, A.log_b) << A.log_c) + c); });
+        } else {
+            head = head_dispatch<F>(A, L.data, false, [&](int p, int c) -> fr29_t {      // point index fastest: contiguous reads
+                return fr29_unpack(ldg(src + (((((k1_0 + c) << A.log_b2) + k2) << A.log_b) + p)));
+            });
+        }
+        lds_barrier();
+        lds_dit<F>(A, L.data, L.tw, head);
+        last_stage<F>(A, L.data, L.tw, head, [&](uint32_t k, int c, const fr29_t& y, bool nrm_out) {
+            const uint64_t o = ((uint64_t)k << (A.log_b1 + A.log_b2)) + (k2 << A.log_b1) + k1_0 + c;
+            fr_t r;
+            if (A.post.lo) r = finish29<F>(y, pow_lookup<F>(A.post, o), nrm_out);
+            else if (A.scale) r = finish29<F>(y, ldg(A.scale), nrm_out);
+            else r = finish29_plain<F>(y);
+            stg(dst + o, r);
+        });
+        lds_barrier();
     }
-    __syncthreads();
-    const int tail = A.log_b >= 3 ? 3 : A.log_b;
-    lds_dif<F>(dlo, dhi, tlo, thi, A.log_b, A.log_c, A.log_b - tail);
-    if (tail == 3) tail_store<F, 3, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
-    else if (tail == 2) tail_store<F, 2, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
-    else if (tail == 1) tail_store<F, 1, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
-    else tail_store<F, 0, false>(A, dlo, dhi, tlo, thi, dst, 0, k1_0, k2);
 }
 
 // Fill a PowTable: lo[i] = c0 * g^i (i < 2^lo_bits), hi[i] = g^(i << lo_bits) (i < 2^hi_bits).

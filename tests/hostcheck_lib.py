@@ -28,6 +28,12 @@ class HostCheck:
     def wide_dot(self, a, b):
         a, b = A(a), A(b); out = np.zeros(4, np.uint64); self.l.hc_wide_dot(P(a), P(b), C.c_size_t(a.shape[0]), P(out)); return out
 
+    def ntt29(self, field, data, inverse=False):
+        """one sub-NTT through the lazy nine-limb butterflies of ntt_dev.hpp (host instantiation); returns (result, max limb, max top limb)"""
+        d = A(data).copy(); log_b = int(d.shape[0]).bit_length() - 1; ml, mt = C.c_uint64(0), C.c_uint64(0)
+        assert self.l.hc_ntt29(field, P(d), log_b, 1 if inverse else 0, C.byref(ml), C.byref(mt)) == 0
+        return d, ml.value, mt.value
+
     def wide_dot32(self, a, b):
         a, b = A(a), A(b); out = np.zeros(4, np.uint64); assert self.l.hc_wide_dot32(P(a), P(b), C.c_size_t(a.shape[0]), P(out)) == 0; return out
 

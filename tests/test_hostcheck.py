@@ -129,3 +129,22 @@ def test_wide_dot_worst_case_and_random(oracle, hostcheck, n):
     if n <= 24:
         assert oracle.to_int(hostcheck.wide_dot32(a, b)) == want
         assert oracle.to_int(hostcheck.wide_dot32(np.tile(top, (n, 1)), np.tile(top, (n, 1)))) == (n * (p - 1) * (p - 1)) % p
+
+
+@pytest.mark.parametrize("field,p", [(0, pyref.P_PALLAS), (1, pyref.P_BLS)])
+def test_lazy_nine_limb_ntt_tile_vs_oracle(oracle, hostcheck, field, p):
+    """The NTT kernels' arithmetic (csrc/ntt_dev.hpp: nine 29-bit limbs, lazily reduced decimation-in-time butterflies, tables carrying the
+    factor 32, carry pass before stages 4/7/10) instantiated on the host: equal to the oracle's radix-2 NTT for every sub-NTT size a pass can
+    take, forward and inverse, on random values and on the worst case (every input r - 1), with the operand bounds the column sums rely on."""
+    rng = random.Random(4242 + field)
+    for log_b in list(range(1, 11)) + [12]:
+        n = 1 << log_b
+        for kind in ("random", "max", "alternating"):
+            if kind == "random": vals = [rng.randrange(p) for _ in range(n)]
+            elif kind == "max": vals = [p - 1] * n
+            else: vals = [(p - 1) if i & 1 else 0 for i in range(n)]
+            x = np.stack([oracle.from_int(v, field) for v in vals])
+            for inverse in (False, True):
+                got, max_limb, max_top = hostcheck.ntt29(field, x, inverse)
+                assert (got == oracle.ntt(field, x, inverse)).all(), (log_b, kind, inverse)
+                assert max_limb <= 6 << 29 and max_top < 1 << 29, (log_b, kind, max_limb, max_top)
