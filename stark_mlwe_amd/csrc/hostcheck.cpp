@@ -109,6 +109,15 @@ template <class F> static int hc_ntt29_impl(uint64_t* data, int log_b, int inver
     return 0;
 }
 extern "C" {
+// fr29_partial_reduce on n lazy nine-limb values (9 x u32 each, any limbs below 2^32 with the value below 2^261): in place
+int hc_partial_reduce(int field, uint32_t* limbs, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        fr29_t x; for (int k = 0; k < 9; ++k) x.l[k] = limbs[9 * i + k];
+        if (field == 0) fr29_partial_reduce<PallasFr>(x); else fr29_partial_reduce<Bls12381Fr>(x);
+        for (int k = 0; k < 9; ++k) limbs[9 * i + k] = x.l[k];
+    }
+    return 0;
+}
 int hc_ntt29(int field, uint64_t* data, int log_b, int inverse, uint64_t* max_limb, uint64_t* max_top) {
     return field == 0 ? hc_ntt29_impl<PallasFr>(data, log_b, inverse, max_limb, max_top) : hc_ntt29_impl<Bls12381Fr>(data, log_b, inverse, max_limb, max_top);
 }

@@ -34,6 +34,11 @@ class HostCheck:
         assert self.l.hc_ntt29(field, P(d), log_b, 1 if inverse else 0, C.byref(ml), C.byref(mt)) == 0
         return d, ml.value, mt.value
 
+    def partial_reduce(self, field, limbs):
+        """fr29_partial_reduce on an (n, 9) uint32 array of lazy nine-limb values"""
+        l = np.ascontiguousarray(limbs, dtype=np.uint32).copy()
+        assert self.l.hc_partial_reduce(field, l.ctypes.data_as(vp), C.c_size_t(l.shape[0])) == 0; return l
+
     def wide_dot32(self, a, b):
         a, b = A(a), A(b); out = np.zeros(4, np.uint64); assert self.l.hc_wide_dot32(P(a), P(b), C.c_size_t(a.shape[0]), P(out)) == 0; return out
 

@@ -148,3 +148,39 @@ def test_lazy_nine_limb_ntt_tile_vs_oracle(oracle, hostcheck, field, p):
                 got, max_limb, max_top = hostcheck.ntt29(field, x, inverse)
                 assert (got == oracle.ntt(field, x, inverse)).all(), (log_b, kind, inverse)
                 assert max_limb <= 6 << 29 and max_top < 1 << 29, (log_b, kind, max_limb, max_top)
+
+
+@pytest.mark.parametrize("field,p", [(0, pyref.P_PALLAS), (1, pyref.P_BLS)])
+def test_partial_reduce_without_product(hostcheck, field, p):
+    """fr29_partial_reduce (the NTT's product-free reduction of a lazy nine-limb value): same residue, limbs below 2^29, result below
+    1.00002 r — for random lazy values up to the 2^261 capacity, for limbs at the 7 * 2^29 bound the butterflies can reach, for exact
+    multiples of r (the quotient estimate must never overshoot), for values just below them and for canonical inputs."""
+    rng = random.Random(77 + field)
+    M = (1 << 29) - 1
+
+    def limbs_of(v, lazy):
+        """nine limbs of v; with `lazy` some weight is moved between neighbours so that limbs exceed 29 bits (value unchanged)"""
+        l = [(v >> (29 * i)) & M for i in range(8)] + [v >> 232]
+        if lazy:
+            for i in range(8):
+                if l[i + 1] > 0 and l[i] + (1 << 29) <= 7 << 29:
+                    k = rng.randrange(0, min(l[i + 1], 6 - (l[i] >> 29)) + 1); l[i + 1] -= k; l[i] += k << 29
+        return l
+
+    cases = []
+    for _ in range(300):
+        cases.append(limbs_of(rng.randrange(1 << 261), rng.random() < 0.7))
+    for k in list(range(0, 70)) + [100, 127]:
+        if k * p < 1 << 261:
+            cases.append(limbs_of(k * p, False))
+            if k: cases.append(limbs_of(k * p - 1, True)); cases.append(limbs_of(k * p + 1, True))
+    cases.append([7 << 29] * 8 + [(1 << 28)])
+    cases.append(limbs_of(p - 1, False)); cases.append([0] * 9)
+    arr = np.array(cases, dtype=np.uint64).astype(np.uint32)
+    assert (arr.astype(np.uint64) == np.array(cases, dtype=np.uint64)).all()
+    out = hostcheck.partial_reduce(field, arr)
+    for lin, lout in zip(cases, out.tolist()):
+        vin = sum(x << (29 * i) for i, x in enumerate(lin)); vout = sum(x << (29 * i) for i, x in enumerate(lout))
+        assert vin < 1 << 261
+        assert vout % p == vin % p
+        assert all(x <= M for x in lout[:8]) and vout < p + (p >> 15), (lin, lout)
