@@ -86,6 +86,9 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     { std::vector<uint32_t> w29; for (auto* v : {&k.lu29, &k.lu_pre29, &k.row0_29, &k.sparse29, &k.gamma29, &k.mds29, &k.mds_pre29}) w29.insert(w29.end(), v->begin(), v->end());
       while (w29.size() % 8) w29.push_back(0);
       blob.resize(o_29 + w29.size() / 8); memcpy((void*)(blob.data() + o_29), w29.data(), w29.size() * 4); }
+    // int8 MFMA fragments of the dense matrices (t = 17), raw bytes in the same blob
+    const size_t o_frag = blob.size(), frag_elems = (k.mds_frag.size() + sizeof(fr_t) - 1) / sizeof(fr_t);
+    if (!k.mds_frag.empty()) { blob.resize(o_frag + 2 * frag_elems); memcpy((void*)(blob.data() + o_frag), k.mds_frag.data(), k.mds_frag.size()); memcpy((void*)(blob.data() + o_frag + frag_elems), k.mds_pre_frag.data(), k.mds_pre_frag.size()); }
     STARK_HIP(ctx, hipMalloc((void**)&P->blob, blob.size() * sizeof(fr_t)));
     STARK_HIP(ctx, hipMemcpyAsync(P->blob, blob.data(), blob.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -96,6 +99,7 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
       P->dev.lu29 = b29; P->dev.lu_pre29 = b29 + k.lu29.size(); P->dev.row0_29 = P->dev.lu_pre29 + k.lu_pre29.size();
       P->dev.sparse29 = P->dev.row0_29 + k.row0_29.size(); P->dev.gamma29 = P->dev.sparse29 + k.sparse29.size();
       P->dev.mds29 = P->dev.gamma29 + k.gamma29.size(); P->dev.mds_pre29 = P->dev.mds29 + k.mds29.size(); }
+    P->dev.mds_frag = k.mds_frag.empty() ? nullptr : (const void*)(P->blob + o_frag); P->dev.mds_pre_frag = k.mds_frag.empty() ? nullptr : (const void*)(P->blob + o_frag + frag_elems);
     return STARK_OK;
 }
 static int32_t params_from_consts(stark_ctx* ctx, const host::PoseidonConsts& c, stark_params** out) {

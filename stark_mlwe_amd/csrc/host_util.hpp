@@ -202,6 +202,8 @@ struct KernelConsts {
     // the multiplier tables of every dot product again, as nine 29-bit limbs of c*2^261 mod r per entry (fr29.hpp)
     std::vector<uint32_t> lu29, lu_pre29, row0_29, sparse29, gamma29;
     std::vector<uint32_t> mds29, mds_pre29;   // dense forms for the one-wave kernel (every entry meets an S-box output: all scaled)
+    // t = 17 only: the dense matrices as int8 MFMA operand fragments (signed radix-256 digits, Toeplitz windows), see mfma_frags
+    std::vector<int8_t> mds_frag, mds_pre_frag;
     bool ok = false;
 };
 // scaled(i) == true: the entry multiplies an S-box output, which fr_pow5_r29 delivers as x^5 / 2^20 (fr29.hpp)
@@ -210,6 +212,26 @@ template <class Pred> inline std::vector<uint32_t> to_radix29(const std::vector<
     std::vector<uint32_t> o(v.size() * 9);
     for (size_t i = 0; i < v.size(); ++i) fr29_const_from<PF>(scaled(i) ? fr_mul<PF>(v[i], k) : v[i], &o[9 * i]);
     return o;
+}
+// A-operand fragments of v_mfma_i32_32x32x32_i8 for y = M * x with x an S-box output (poseidon_pair.hpp pair_apply_mds_mfma).
+// Entry (i, e) is c = M[i][e] * 2^20 * 32 in Montgomery form (2^20: fr_pow5_r29's scale; 32: the Montgomery step by 2^261 instead of 2^256),
+// written in SIGNED radix-256 digits d[0..31] in [-128, 127] (add 0x80 to every byte with carries, subtract 0x80 from every digit; c < r
+// keeps the top byte below 0x80, so no 33rd digit).  The product's digit-column sums are S[c] = sum_{e,b} d_ie[c - b] * xd_e[b]: row c of
+// a Toeplitz matrix.  Fragment ((i*2 + rt)*t + e) holds, for lane l (tile row r = l & 31, k half kh = l >> 5), the 16 bytes
+// j -> d_ie[(32 rt + r) - (16 kh + j)] (zero outside 0..31): the left operand of the K-step of element e for the output digits 32 rt .. 32 rt + 31.
+inline std::vector<int8_t> mfma_frags(const std::vector<fr_t>& mat, int t) {
+    std::vector<int8_t> out((size_t)t * 2 * t * 64 * 16, 0);
+    const fr_t scale = h_mul(fr_from_u64<PF>(1ull << FR29_SBOX_SHIFT), fr_from_u64<PF>(32));
+    for (int i = 0; i < t; ++i) for (int e = 0; e < t; ++e) {
+        const fr_t c = h_mul(mat[(size_t)i * t + e], scale);
+        int8_t d[32]; int cy = 0;
+        for (int b = 0; b < 32; ++b) { const int v = (int)((c.v[b >> 2] >> (8 * (b & 3))) & 0xff) + 0x80 + cy; cy = v >> 8; d[b] = (int8_t)((v & 0xff) - 0x80); }
+        for (int rt = 0; rt < 2; ++rt) for (int l = 0; l < 64; ++l) for (int j = 0; j < 16; ++j) {
+            const int idx = (32 * rt + (l & 31)) - (16 * (l >> 5) + j);
+            out[(((size_t)(i * 2 + rt) * t + e) * 64 + l) * 16 + j] = (idx >= 0 && idx < 32) ? d[idx] : (int8_t)0;
+        }
+    }
+    return out;
 }
 // Gauss-Jordan inverse of an n x n matrix (row-major); returns false when singular.
 inline bool mat_inverse(std::vector<fr_t> a, int n, std::vector<fr_t>& inv) {
@@ -285,6 +307,7 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     k.lu29 = to_radix29(k.lu, upper); k.lu_pre29 = to_radix29(k.lu_pre, upper); k.row0_29 = to_radix29(k.row0, all);
     k.sparse29 = to_radix29(k.sparse, a_and_w); k.gamma29 = to_radix29(k.gamma, all);
     k.mds29 = to_radix29(k.mds, all); k.mds_pre29 = to_radix29(k.mds_pre, all);
+    if (t == 17) { k.mds_frag = mfma_frags(k.mds, t); k.mds_pre_frag = mfma_frags(k.mds_pre, t); }      // the wave-pair kernels' full rounds (poseidon_pair.hpp)
     k.ok = true;
     return k;
 }

@@ -77,10 +77,98 @@ __device__ __forceinline__ void pair_apply_lu(const PairState& s, const uint32_t
     }
     __syncthreads();
 }
-template <int T>
+// x (canonical) -> signed radix-256 digits in place of its bytes: add 0x80 to every byte with carries, flip every byte's top bit
+// (digit b = byte b - 0x80 in [-128, 127]; x < r keeps the top byte below 0x80, so 32 digits hold it).  The int8 operand form of the MFMA product.
+__device__ __forceinline__ fr_t recode_signed(const fr_t& x) {
+    fr_t y; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)x.v[i] + 0x80808080u + c; y.v[i] = (uint32_t)t ^ 0x80808080u; c = t >> 32; }
+    return y;
+}
+template <int T, bool RECODE = false>
 __device__ __forceinline__ void pair_sbox_full(const PairState& s, const fr_t* rc) {
     const int j0 = s.isY ? PairCfg<T>::NX : 0, j1 = s.isY ? T : PairCfg<T>::NX;
-    for (int j = j0; j < j1; ++j) s.sto(j, fr_pow5_r29<PF>(fr_add<PF>(s.ld(j), rc[j])));
+    for (int j = j0; j < j1; ++j) { const fr_t x = fr_pow5_r29<PF>(fr_add<PF>(s.ld(j), rc[j])); s.sto(j, RECODE ? recode_signed(x) : x); }
+    __syncthreads();
+}
+
+// ---- the dense full-round product on the matrix cores (T = 17) ---------------------------------------------------------------------
+// y = M * x for the 64 sponges of the pair, x = the S-box outputs, stored RECODED (signed digits) in the state slots.  With both factors in
+// signed radix-256 digits the digit-column sums S[(i,c)][n] = sum_{e,b} d_ie[c-b] * xd_e[n][b] are one int8 matrix product with a Toeplitz
+// left factor (host_util.hpp mfma_frags), |S| < 2^24: exact in the i32 accumulators of v_mfma_i32_32x32x32_i8.
+//   * B operand: lane l holds, for element e and column tile ct, the 16 bytes of half (l >> 5) of element e of sponge 32 ct + (l & 31) — exactly one
+//     16-byte state slot.  A wave keeps the whole state in registers (17 x 2 x 4 VGPRs): every A fragment then feeds 4 MFMAs (1 KB of L2 traffic per
+//     128 cycles of matrix pipe; less reuse is L1-bound, tools/mfma_dense.hip).
+//   * X takes the even outputs, Y the odd ones.  Per output: 68 MFMAs into 2 x 2 tiles (digits 0..31 / 32..63 x sponges 0..31 / 32..63).
+//   * D layout: lane l, register r = row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of column l & 31: a sponge's 64 digit sums sit in lanes l and l + 32.
+//     v_permlane32_swap(tile of sponges 0..31, tile of sponges 32..63) hands the lower lane the upper lane's rows of ITS sponge and vice versa, so
+//     that afterwards lane l owns sponge l (the kernels' lane <-> sponge map) with the rows in a lane-uniform order.
+//   * fold: pairs of adjacent digit sums (S0 + 256 S1 < 2^33) are shifted into the 64-bit column of weight 2^(29k) that holds the lower digit; a
+//     signed carry pass (the total is a non-negative integer) leaves 29-bit limbs, and the usual Montgomery step by 2^261 returns y canonical.
+// 95 k SIMD-cycles per product against ~180 k for the in-place L*U form (tools/mfma_mds.hip, profiles/r02_mfma_mds_end_to_end_prototype.jsonl).
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void mfma_fold_rows(int64_t* col, const mfma_v16i& lo, const mfma_v16i& hi, int rt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const mfma_v16i& a = hh ? hi : lo;
+                const int64_t pair = (int64_t)a[4 * q + 2 * p] + (int64_t)a[4 * q + 2 * p + 1] * 256;
+                const int c = 32 * rt + 8 * q + 4 * hh + 2 * p, k = (8 * c) / 29, sh = 8 * c - 29 * k;
+                col[k] += pair << sh;
+            }
+}
+// Precondition: every state slot holds a recoded S-box output and a barrier has passed.  Ends with the state canonical and consistent.
+__device__ __forceinline__ void pair_apply_mds_mfma(const PairState& s, const void* frag) {
+    constexpr int T = 17;
+    const int lane = s.lane, h = lane >> 5;
+    mfma_v4i b[T][2];
+#pragma unroll
+    for (int e = 0; e < T; ++e)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { const uint4 u = s.st[(2 * e + h) * 64 + 32 * ct + (lane & 31)]; b[e][ct] = mfma_v4i{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
+    __syncthreads();                                   // both waves hold the state: the slots may be overwritten
+    const mfma_v4i* A = reinterpret_cast<const mfma_v4i*>(frag) + lane;
+#pragma unroll 1
+    for (int i = s.isY ? 1 : 0; i < T; i += 2) {
+        mfma_v16i acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0;
+        const mfma_v4i* Ai = A + (size_t)(i * 2) * T * 64;
+#pragma unroll
+        for (int e = 0; e < T; ++e) {
+            const mfma_v4i a0 = Ai[(size_t)e * 64], a1 = Ai[(size_t)(T + e) * 64];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[e][ct], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[e][ct], acc[1][ct], 0, 0, 0);
+            }
+        }
+        mfma_v16i lo[2], hi[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)acc[rt][0][r], (unsigned)acc[rt][1][r], false, false);
+                lo[rt][r] = (int)sw[0]; hi[rt][r] = (int)sw[1];
+            }
+        int64_t col[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) col[k] = 0;
+        mfma_fold_rows(col, lo[0], hi[0], 0); mfma_fold_rows(col, lo[1], hi[1], 1);
+        fr_wide29 w;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) { col[k + 1] += col[k] >> 29; w.c[k] = (uint64_t)col[k] & FR_M29; }
+        w.c[17] = (uint64_t)col[17];
+        s.sto(i, fr_wide29_reduce<PF>(w));
+    }
     __syncthreads();
 }
 
@@ -102,8 +190,8 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
     constexpr int NXD = Cfg::NXD, NXU = Cfg::NXU, W = 2 * T - 1;
     const int half = P.rf / 2;
     for (int r = r_begin; r < half; ++r) {
-        pair_sbox_full<T>(s, P.rc_full + r * T);
-        pair_apply_lu<T>(s, (r == half - 1) ? P.lu_pre29 : P.lu29);
+        if constexpr (T == 17) { pair_sbox_full<T, true>(s, P.rc_full + r * T); pair_apply_mds_mfma(s, (r == half - 1) ? P.mds_pre_frag : P.mds_frag); }
+        else { pair_sbox_full<T>(s, P.rc_full + r * T); pair_apply_lu<T>(s, (r == half - 1) ? P.lu_pre29 : P.lu29); }
     }
     fr_t s0 = fr_zero<PF>();
     if (!s.isY) s0 = s.ld(0);
@@ -163,8 +251,10 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
     if (!s.isY) s.sto(0, s0);
     __syncthreads();
     for (int r = half; r < P.rf; ++r) {
-        pair_sbox_full<T>(s, P.rc_full + r * T);
-        if (only0 && r == P.rf - 1) {                       // squeeze: row 0 only, split over the two waves
+        const bool squeeze = only0 && r == P.rf - 1;
+        if constexpr (T == 17) { if (squeeze) pair_sbox_full<T>(s, P.rc_full + r * T); else pair_sbox_full<T, true>(s, P.rc_full + r * T); }
+        else pair_sbox_full<T>(s, P.rc_full + r * T);
+        if (squeeze) {                                      // squeeze: row 0 only, split over the two waves
             const int j0 = s.isY ? Cfg::NX : 0, j1 = s.isY ? T : Cfg::NX;
             DotAcc acc; acc.init();
 #pragma unroll 1
@@ -175,7 +265,7 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
             __syncthreads();                                 // the slots are reused by the next permutation
             return out;
         }
-        pair_apply_lu<T>(s, P.lu29);
+        if constexpr (T == 17) pair_apply_mds_mfma(s, P.mds_frag); else pair_apply_lu<T>(s, P.lu29);
     }
     return s.ld(0);
 }

@@ -16,6 +16,7 @@ struct PoseidonDev {           // device pointers to kernel-form constants (see 
     // the same multiplier tables in radix 2^29, R' = 2^261 domain, 9 words per entry (fr29.hpp): what the dot products read
     const uint32_t* lu29; const uint32_t* lu_pre29; const uint32_t* row0_29; const uint32_t* sparse29; const uint32_t* gamma29;
     const uint32_t* mds29; const uint32_t* mds_pre29;   // dense M and B_1*M (one-wave kernel)
+    const void* mds_frag; const void* mds_pre_frag;     // t = 17: the same two matrices as int8 MFMA fragments (host_util.hpp mfma_frags); nullptr otherwise
 };
 
 }  // namespace stark

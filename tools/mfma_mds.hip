@@ -23,21 +23,23 @@ __device__ __forceinline__ fr_t recode_signed(const fr_t& x) {
     for (int i = 0; i < 8; ++i) { const uint64_t s = (uint64_t)x.v[i] + 0x80808080u + c; y.v[i] = (uint32_t)s ^ 0x80808080u; c = s >> 32; }
     return y;
 }
-// digit sums of one 32x32 tile pair -> 64-bit columns of weight 2^(29k).  Lane half h holds rows (reg&3) + 8(reg>>2) + 4h of each tile; row = digit position c - 32*rt.
-__device__ __forceinline__ void fold_tile(int64_t* col, const v16i& acc, int rt, int h) {
+// After the half exchange a lane holds all 64 digit sums of ITS sponge: lo[rt][reg] = rows (reg&3) + 8(reg>>2) of tile rt (the lower lane's
+// rows), hi[rt][reg] = the same + 4 (the upper lane's rows); row = digit position c - 32 rt.  Pairs of adjacent digits go into the 64-bit
+// column of weight 2^(29k) that holds the lower one (shift < 29, pair below 2^33: no overflow).
+__device__ __forceinline__ void fold_rows(int64_t* col, const v16i& lo, const v16i& hi, int rt) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {      // rows 8q + 4h + 2p, + 1: one 64-bit pair value S0 + 256 * S1
-            const int64_t pair = (int64_t)acc[4 * q + 2 * p] + (int64_t)acc[4 * q + 2 * p + 1] * 256;
-            // c depends on h (lane half): two compile-time candidates, selected per lane
-            const int c0 = 32 * rt + 8 * q + 2 * p, c1 = c0 + 4;
-            const int k0 = (8 * c0) / 29, s0 = 8 * c0 - 29 * k0, k1 = (8 * c1) / 29, s1 = 8 * c1 - 29 * k1;
-            if (k0 == k1) col[k0] += pair << (h ? s1 : s0);
-            else { if (h) col[k1] += pair << s1; else col[k0] += pair << s0; }
-        }
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const v16i& a = hh ? hi : lo;
+                const int64_t pair = (int64_t)a[4 * q + 2 * p] + (int64_t)a[4 * q + 2 * p + 1] * 256;
+                const int c = 32 * rt + 8 * q + 4 * hh + 2 * p, k = (8 * c) / 29, sh = 8 * c - 29 * k;
+                col[k] += pair << sh;
+            }
 }
-__global__ void __launch_bounds__(128) k_mds(const v4i* __restrict__ Atab, const fr_t* __restrict__ X, fr_t* __restrict__ Y, int reps) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) k_mds(const v4i* __restrict__ Atab, const fr_t* __restrict__ X, fr_t* __restrict__ Y, int reps) {
     __shared__ uint4 st[T * 2 * 64];
     const int lane = threadIdx.x & 63, h = lane >> 5; const bool isY = threadIdx.x >= 64;
     const size_t b0 = (size_t)blockIdx.x * T * 64;
@@ -53,6 +55,7 @@ __global__ void __launch_bounds__(128) k_mds(const v4i* __restrict__ Atab, const
         for (int ct = 0; ct < 2; ++ct) { const uint4 u = st[(2 * e + h) * 64 + 32 * ct + (lane & 31)]; b[e][ct] = v4i{(int)u.x, (int)u.y, (int)u.z, (int)u.w}; }
     __syncthreads();
     for (int rep = 0; rep < reps; ++rep)
+#pragma unroll 1
     for (int i = isY ? 1 : 0; i < T; i += 2) {
         v16i acc[2][2];
 #pragma unroll
@@ -61,31 +64,35 @@ __global__ void __launch_bounds__(128) k_mds(const v4i* __restrict__ Atab, const
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0;
+        const v4i* Ai = Atab + (size_t)(i * 2) * T * 64 + lane;
 #pragma unroll
         for (int e = 0; e < T; ++e) {
-            const v4i a0 = Atab[((size_t)(i * 2 + 0) * T + e) * 64 + lane], a1 = Atab[((size_t)(i * 2 + 1) * T + e) * 64 + lane];
+            const v4i a0 = Ai[(size_t)e * 64], a1 = Ai[(size_t)(T + e) * 64];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 acc[0][ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[e][ct], acc[0][ct], 0, 0, 0);
                 acc[1][ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[e][ct], acc[1][ct], 0, 0, 0);
             }
         }
-        // fold both column tiles, exchange halves: lane l (< 32) owns sponge l = column tile 0, lane 32 + l owns sponge 32 + l = column tile 1
-        int64_t U[18], V[18];
+        // half exchange: lane l (< 32) owns sponge l = column tile 0, lane 32 + l owns sponge 32 + l = column tile 1.  swap(vdst = tile 0, src0 = tile 1)
+        // gives the lower lane the upper lane's tile-0 rows and the upper lane the lower lane's tile-1 rows: afterwards r[0] = the lower rows, r[1] = the upper rows of the own sponge
+        v16i lo[2], hi[2];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) { U[k] = 0; V[k] = 0; }
-        fold_tile(U, acc[0][0], 0, h); fold_tile(U, acc[1][0], 1, h); fold_tile(V, acc[0][1], 0, h); fold_tile(V, acc[1][1], 1, h);
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)acc[rt][0][r], (unsigned)acc[rt][1][r], false, false);
+                lo[rt][r] = (int)sw[0]; hi[rt][r] = (int)sw[1];
+            }
+        int64_t col[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) col[k] = 0;
+        fold_rows(col, lo[0], hi[0], 0); fold_rows(col, lo[1], hi[1], 1);
         fr_wide29 w;
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)(uint64_t)U[k], (unsigned)(uint64_t)V[k], false, false);
-            const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)((uint64_t)U[k] >> 32), (unsigned)((uint64_t)V[k] >> 32), false, false);
-            const int64_t r0 = (int64_t)(((uint64_t)hi[0] << 32) | lo[0]), r1 = (int64_t)(((uint64_t)hi[1] << 32) | lo[1]);
-            w.c[k] = (uint64_t)(r0 + r1);
-        }
         // signed carry pass: the total is a non-negative integer, so every limb ends in [0, 2^29) and the top column non-negative
 #pragma unroll
-        for (int k = 0; k < 17; ++k) { const int64_t v = (int64_t)w.c[k]; w.c[k + 1] = (uint64_t)((int64_t)w.c[k + 1] + (v >> 29)); w.c[k] = (uint64_t)v & FR_M29; }
+        for (int k = 0; k < 17; ++k) { col[k + 1] += col[k] >> 29; w.c[k] = (uint64_t)col[k] & FR_M29; }
+        w.c[17] = (uint64_t)col[17];
         const fr_t y = fr_wide29_reduce<F>(w);
         if (rep == 0) Y[b0 + (size_t)i * 64 + lane] = y;
     }
