@@ -37,22 +37,30 @@ LOG_BLOWUP = 3
 SCHEDULE = [16, 16, 8]
 SEED_Z = 0xDEEFBAAD
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_I8_PEAK_MACS = 2.5e15      # dense int8 MAC/s: twice the bf16 rate (MI355X_MICROARCH.md: about 2.5 PFLOP/s bf16 dense = 1.25 PMAC/s)
 FR_MULTS_T17, FR_MULTS_T9 = 21408, 5904   # reference-dense Fr-mults per permutation
 P_PALLAS = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
 
 
 def leaf_kernel_macs():
-    """Algorithmic 32x32+64 multiply-accumulates of ONE leaf hash in kernel form, radix-2^29 arithmetic:
-    a dot-product term is 9x9 = 81 MACs, a square 45, a Montgomery step 36 (nine digits x four non-trivial limbs of r).
-    t = 17, RF = 8, RP = 64: full rounds = 17 S-boxes + a dense 17x17 product (as L*U in place: 17*17 terms, 2*17 reductions);
-    partial rounds in blocks of 4: 2t-1 = 33 terms + 1.5 cross terms per round, 5 reductions per round, one S-box.
-    The leaf kernel's round 0 is a closed form: 2 S-boxes and 2 terms per lane instead of 17 S-boxes and 289 terms."""
+    """Algorithmic multiply-accumulates of ONE leaf hash in kernel form.  Returns (valu, mfma):
+    valu = 32x32+64 MACs on the vector ALU (v_mad_u64_u32), radix-2^29 arithmetic: a dot-product term is 9x9 = 81 MACs, a square 45, a
+    Montgomery step 36 (nine digits x four non-trivial limbs of r);
+    mfma = int8 MACs on the matrix cores: the six dense full-round products of a leaf hash run as v_mfma_i32_32x32x32_i8 over signed
+    radix-256 digits — per product and sponge 17 outputs x 64 digit positions x (17 elements x 32 digits) MACs (half of them on the
+    structural zeros of the Toeplitz operand: counted, they occupy the pipe).
+    t = 17, RF = 8, RP = 64.  VALU share of a full round: 17 S-boxes + 17 Montgomery steps of the product's outputs; partial rounds in blocks of 4:
+    2t-1 = 33 terms + 1.5 cross terms per round, 5 reductions per round, one S-box; the last full round squeezes row 0 only (17 terms, 2
+    reductions); the leaf kernel's round 0 is a closed form: 2 S-boxes and 2 terms per lane instead of 17 S-boxes and a dense product."""
     t, rf, rp = 17, 8, 64
     sbox = 2 * 45 + 81 + 3 * 36
-    full = t * sbox + t * t * 81 + 2 * t * 36
+    full_valu = t * sbox + t * 36                       # rounds 1..6: the product itself is on the matrix cores
+    last = t * sbox + t * 81 + 2 * 36                   # round 7: row 0 only
     part = sbox + (2 * t - 1 + 1.5) * 81 + 5 * 36
     round0 = 2 * sbox + 2 * t * 81 + t * 36
-    return (rf - 1) * full + round0 + rp * part
+    valu = (rf - 2) * full_valu + last + round0 + rp * part
+    mfma = (rf - 2) * t * 64 * (t * 32)
+    return valu, mfma
 
 
 def main():
@@ -257,16 +265,21 @@ def main():
                 traffic = json.load(open(tpath)).get(f"ntt_2^{log_n + LOG_BLOWUP}_bytes_per_transform")
             except Exception:
                 traffic = None
-        macs_leaf = leaf_kernel_macs()
+        macs_leaf, mfma_leaf = leaf_kernel_macs()
+        leaves_per_s = N / (leaf_ms * 1e-3)
         out.update({
             "roofline": {"bound": "hbm", "kernel": f"Fr-NTT 2^{log_n + LOG_BLOWUP} coset forward (k_ntt_strided x2 + k_ntt_last)", "achieved": ntt_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ntt_gbps / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes": ntt_bytes, "avg_ms": ntt_ms,
                          "lde_2^%d_to_2^%d_ms_per_column" % (log_n, log_n + LOG_BLOWUP): lde_ms},
-            "poseidon": {"kernel": "k_leaf_pair2 (t=17), 2^%d leaves" % (log_n + LOG_BLOWUP), "ms": leaf_ms, "leaves_per_s": N / (leaf_ms * 1e-3),
-                         "reference_dense_fr_mults_per_s": FR_MULTS_T17 * N / (leaf_ms * 1e-3),
+            "poseidon": {"kernel": "k_leaf_pair2 (t=17), 2^%d leaves" % (log_n + LOG_BLOWUP), "ms": leaf_ms, "leaves_per_s": leaves_per_s,
+                         "reference_dense_fr_mults_per_s": FR_MULTS_T17 * leaves_per_s,
                          "roofline": {"bound": "int-valu", "unit": "lane-MAC/s (v_mad_u64_u32)", "peak": mac_rate.value, "peak_source": "stark_diag_mac_rate, measured live on this device",
-                                      "macs_per_leaf": macs_leaf, "achieved": macs_leaf * N / (leaf_ms * 1e-3), "frac": macs_leaf * N / (leaf_ms * 1e-3) / mac_rate.value,
-                                      "share_of_step": leaf_ms / ms_per_step if world == 1 else None}},
+                                      "macs_per_leaf": macs_leaf, "achieved": macs_leaf * leaves_per_s, "frac": macs_leaf * leaves_per_s / mac_rate.value,
+                                      "share_of_step": leaf_ms / ms_per_step if world == 1 else None,
+                                      "note": "the vector-ALU part of the kernel; its six dense full-round products run on the matrix cores (mfma_i8 below) and overlap with it",
+                                      "mfma_i8": {"unit": "int8 MAC/s (v_mfma_i32_32x32x32_i8)", "macs_per_leaf": mfma_leaf, "achieved": mfma_leaf * leaves_per_s,
+                                                  "peak": MFMA_I8_PEAK_MACS, "frac": mfma_leaf * leaves_per_s / MFMA_I8_PEAK_MACS,
+                                                  "peak_source": "MI355X_MICROARCH.md: dense int8 = 2x the bf16 rate (about 2.5 PFLOP/s bf16 = 1.25 PMAC/s)"}}},
         })
         out.update(sections)
         if not args.no_cpu_baseline and world == 1:
