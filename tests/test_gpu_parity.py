@@ -88,6 +88,30 @@ def test_tr_hash_fields_tagged(gpu_ctx, oracle):
         assert (got[i] == oracle.tr_hash_fields_tagged(b"FRI/index", batch[3 * i:3 * i + 3])).all()
 
 
+def test_throughput_kernels_on_extreme_field_values(gpu_ctx, oracle):
+    """The wave-pair kernels' full rounds multiply on the int8 matrix cores over SIGNED radix-256 digits (poseidon_pair.hpp): inputs whose
+    bytes sit at the recoding's corners — 0, 1, r - 1, r - 2, all-0x7f / all-0x80 / all-0xff byte patterns (reduced below r), single high
+    bits — through the leaf hash (k_leaf_pair2) and through an arity-16 Merkle tree of 2^18 leaves, whose first level (16 384 nodes, above
+    the one-wave threshold) runs k_hash_ds2<17>, against the oracle."""
+    import pyref
+    p = pyref.P_PALLAS
+    pats = [0, 1, 2, p - 1, p - 2, p - 3, (p - 1) // 2, (p + 1) // 2]
+    pats += [int.from_bytes(bytes([b]) * 32, "little") % p for b in (0x7f, 0x80, 0x81, 0xff, 0x01, 0xfe)]
+    pats += [(1 << k) % p for k in (7, 8, 15, 31, 63, 127, 128, 253)] + [((1 << k) - 1) % p for k in (8, 64, 128, 254)]
+    vals = np.stack([oracle.from_int(v) for v in pats])
+    n = 1 << 13
+    rng = np.random.default_rng(7)
+    f = vals[rng.integers(0, len(vals), n)]; fn = vals[rng.integers(0, len(vals), n // 16)]
+    f[:len(vals)] = vals
+    assert (gpu_ctx.leaf_pair_hash(f, fn, 16) == oracle.leaf_pair_hash(f, fn, 16)).all()
+    assert (gpu_ctx.leaf_pair_hash(f, None, 1) == oracle.leaf_pair_hash(f, None, 1)).all()
+    big = np.concatenate([f] * 32)                      # 2^18 leaves
+    t = gpu_ctx.merkle_new(big, gpu_ctx.merkle_cfg(16, 3)); o = oracle.merkle_build(16, 3, big)
+    for lvl in range(o.num_levels()):
+        assert (t.level(lvl) == o.level(lvl)).all(), lvl
+    t.free(); o.free()
+
+
 # ---- Merkle ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("arity,n,label", [(16, 4096, 0), (16, 55, 9), (16, 64, 42), (8, 512, 2), (8, 19, 3), (2, 8, 1), (4, 64, 7), (16, 1, 5), (32, 1024, 4)])
 def test_merkle_tree_levels(gpu_ctx, oracle, arity, n, label):
