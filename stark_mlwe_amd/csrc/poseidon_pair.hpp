@@ -6,9 +6,11 @@
 // waves per SIMD).  Here a workgroup is a pair of waves (X, Y) that share the 64 LDS-resident states of
 // the batch: lane l of both waves works on state l, each wave on its own part of the linear algebra.
 // Same LDS per state, twice the waves per SIMD (4 workgroups of 40 KiB per CU for t = 17).
-//   * full rounds : S-box on the wave's own elements; the dense MDS as in-place L*(U*x), X taking the
-//                   even rows and Y the odd rows of each step (rows 2k/2k+1 read only slots >= 2k, so a
-//                   single barrier between the step's reads and its two writes keeps it race-free);
+//   * full rounds : S-box on the wave's own elements; the dense MDS product
+//                   - t = 17: on the MATRIX CORES (pair_apply_mds_mfma below): int8 MFMA over signed radix-256 digits, X the even
+//                     output rows, Y the odd ones, each wave holding the whole state as operand registers;
+//                   - t = 9: as in-place L*(U*x) on the VALU, X taking the even rows and Y the odd rows of each step (rows
+//                     2k/2k+1 read only slots >= 2k, so a single barrier between the step's reads and its two writes keeps it race-free);
 //   * partial rounds, in blocks of 4 (see permute_core in poseidon_dev.hpp for the algebra):
 //       phase 1  X runs the S-box chain: x_q, then a_q x_q + sum_{p<q} gamma x_p + its quarter of the
 //                lane dot product from registers; Y computes the other three quarters of every round's
