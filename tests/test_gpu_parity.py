@@ -112,6 +112,22 @@ def test_throughput_kernels_on_extreme_field_values(gpu_ctx, oracle):
     t.free(); o.free()
 
 
+def test_wave_pair_level_with_other_t17_constants(gpu_ctx, oracle):
+    """The int8 fragments of the dense matrices are derived per parameter set: a Merkle level large enough for the wave-pair kernel
+    (2^14 + 3 nodes, ragged last node) hashed with the `POSEIDON-T17-X5` parameters of the reference's bench (poseidon/benches/poseidon.rs:6-15)
+    instead of the Merkle defaults, against the oracle's hash_with_ds_dynamic with the same constants on sampled nodes."""
+    p = gpu_ctx.generate_params_t17_x5(b"POSEIDON-T17-X5")
+    nodes = (1 << 14) + 3
+    ch = oracle.synth_column(77, 2, 0, (nodes - 1) * 16 + 5)
+    got = gpu_ctx.hash_ds_level(p, 16, 4, 100, 42, ch)
+    assert got.shape[0] == nodes
+    for k in (0, 1, 63, 64, 8191, 8192, nodes - 2, nodes - 1):
+        kids = ch[16 * k: 16 * k + 16]
+        ds = np.array([F(oracle, 16), F(oracle, 4), F(oracle, 100 + k), F(oracle, 42)])
+        assert (got[k] == oracle.hash_with_ds_dynamic(3, 17, ds, kids, kids.shape[0])).all(), k
+    p.free()
+
+
 # ---- Merkle ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("arity,n,label", [(16, 4096, 0), (16, 55, 9), (16, 64, 42), (8, 512, 2), (8, 19, 3), (2, 8, 1), (4, 64, 7), (16, 1, 5), (32, 1024, 4)])
 def test_merkle_tree_levels(gpu_ctx, oracle, arity, n, label):
