@@ -12,6 +12,7 @@
 #include "poseidon_dev.hpp"
 #include "fri_plan.hpp"
 #include "fri_verify.hpp"
+#include "mfma_digits.hpp"
 
 using namespace stark;
 
@@ -139,6 +140,39 @@ int hc_params_export(void* h, uint64_t* mds, uint64_t* rc_full, uint64_t* rc_par
     for (size_t i = 0; i < P->ref.mds.size(); ++i) st4(mds + 4 * i, P->ref.mds[i]);
     for (size_t i = 0; i < P->ref.rc_full.size(); ++i) st4(rc_full + 4 * i, P->ref.rc_full[i]);
     for (size_t i = 0; i < P->ref.rc_partial.size(); ++i) st4(rc_partial + 4 * i, P->ref.rc_partial[i]);
+    return 0;
+}
+// One full round's linear layer  y = M * x  (x = S-box outputs) of t = 17 states, two ways on the host: through the in-place L*U rows the VALU
+// kernels use (which = 0), and through an emulation of the matrix-core path (which = 1): signed recoding, the int8 FRAGMENT TABLES the kernels
+// read (host_util.hpp mfma_frags: lane l of fragment (i, rt, e) holds A[row l & 31][k = 16 (l >> 5) + j]), D[row][col] = sum_k A[row][k] B[k][col]
+// per tile, the accumulator rows as the two lanes of a sponge receive them, the fold and the Montgomery step of mfma_digits.hpp.  pre: the B_1 * M matrix.
+int hc_full_round_linear(void* h, int which, int pre, uint64_t* states, size_t n) {
+    HcParams* P = (HcParams*)h; const int t = P->dev.t;
+    if (t != 17 || P->kc.mds_frag.empty()) return -1;
+    std::vector<fr_t> st(t), out(t);
+    const std::vector<int8_t>& F = pre ? P->kc.mds_pre_frag : P->kc.mds_frag;
+    for (size_t s = 0; s < n; ++s) {
+        for (int j = 0; j < t; ++j) st[j] = ld4(states + 4 * (s * t + j));
+        if (which == 0) { ArrayState a{st.data()}; apply_lu(a, pre ? P->dev.lu_pre29 : P->dev.lu29, t); out = st; }
+        else {
+            std::vector<fr_t> xd(t); for (int e = 0; e < t; ++e) xd[e] = recode_signed(st[e]);
+            for (int i = 0; i < t; ++i) {
+                int64_t col[18]; for (int k = 0; k < 18; ++k) col[k] = 0;
+                for (int rt = 0; rt < 2; ++rt) {
+                    int32_t S[32];
+                    for (int r = 0; r < 32; ++r) { int64_t acc = 0;
+                        for (int e = 0; e < t; ++e) for (int kh = 0; kh < 2; ++kh) { const int8_t* a = &F[((((size_t)(i * 2 + rt) * t + e) * 64) + (r + 32 * kh)) * 16];
+                            const int8_t* b = reinterpret_cast<const int8_t*>(xd[e].v) + 16 * kh; for (int j = 0; j < 16; ++j) acc += (int64_t)a[j] * b[j]; }
+                        if (acc > 0x7fffffffll || acc < -0x80000000ll) return -2; S[r] = (int32_t)acc; }
+                    int32_t lo[16], hi[16];
+                    for (int reg = 0; reg < 16; ++reg) { const int row = (reg & 3) + 8 * (reg >> 2); lo[reg] = S[row]; hi[reg] = S[row + 4]; }
+                    mfma_fold_rows(col, lo, hi, rt);
+                }
+                out[i] = mfma_finish_cols(col);
+            }
+        }
+        for (int j = 0; j < t; ++j) st4(states + 4 * (s * t + j), out[j]);
+    }
     return 0;
 }
 // kernel-form permutation (LU + sparse) of nstates AoS states on the host

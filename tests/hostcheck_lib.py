@@ -68,6 +68,11 @@ class HostCheck:
     def permute_kernel_form(self, h, states, t):
         s = A(states).copy(); self.l.hc_permute_kernel_form(h, P(s), C.c_size_t(s.size // (4 * t))); return s
 
+    def full_round_linear(self, h, which, pre, states):
+        """y = M x of t = 17 states of S-box outputs: which = 0 the L*U rows, 1 the emulated matrix-core path (fragment tables, fold)"""
+        s = A(states).copy(); rc = self.l.hc_full_round_linear(h, which, 1 if pre else 0, P(s), C.c_size_t(s.size // (17 * 4)))
+        assert rc == 0, rc; return s
+
     def permute_dense(self, h, states, t):
         s = A(states).copy(); self.l.hc_permute_dense(h, P(s), C.c_size_t(s.size // (4 * t))); return s
 

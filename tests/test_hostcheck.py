@@ -184,3 +184,23 @@ def test_partial_reduce_without_product(hostcheck, field, p):
         assert vin < 1 << 261
         assert vout % p == vin % p
         assert all(x <= M for x in lout[:8]) and vout < p + (p >> 15), (lin, lout)
+
+
+def test_matrix_core_full_round_tables_and_fold(oracle, hostcheck):
+    """The t = 17 wave-pair kernels multiply the full rounds' dense matrices on the int8 matrix cores (poseidon_pair.hpp).  Everything of that path
+    that is not the MFMA instruction itself is host-checkable: the signed radix-256 recoding, the Toeplitz FRAGMENT TABLES (host_util.hpp mfma_frags,
+    emulated as D[row][col] = sum_k A[row][k] B[k][col] over the tables' lane layout), the accumulator-row order the lanes see, the fold into 29-bit
+    columns, the signed carry pass and the Montgomery step.  Equal to the L*U rows of the VALU path on random S-box outputs and on the corners of the
+    recoding (0, r - 1, 0x7f / 0x80 / 0xff byte patterns), for M and for B_1 * M, with the Merkle and the transcript parameter sets."""
+    p = pyref.P_PALLAS
+    rng = random.Random(1717)
+    corner = [0, 1, p - 1, p - 2, (p - 1) // 2] + [int.from_bytes(bytes([b]) * 32, "little") % p for b in (0x7f, 0x80, 0x81, 0xff)]
+    for kind in (0, 1):
+        h = hostcheck.params(kind, 17)
+        vals = [[rng.randrange(p) for _ in range(17)] for _ in range(6)] + [[corner[(i + j) % len(corner)] for j in range(17)] for i in range(4)]
+        st = np.stack([np.stack([oracle.from_int(v) for v in row]) for row in vals])
+        for pre in (False, True):
+            a = hostcheck.full_round_linear(h, 0, pre, st); b = hostcheck.full_round_linear(h, 1, pre, st)
+            assert (a == b).all(), (kind, pre)
+            assert not (a == st).all()
+        hostcheck.params_free(h)
