@@ -315,6 +315,19 @@ def test_ntt_large_vs_oracle_and_properties(gpu_ctx, oracle, lg):
     assert (yd[0] == oracle.from_u64(1)).all() and (yd[1] == w).all() and (yd[2] == oracle.mul(w, w)).all()
 
 
+@pytest.mark.parametrize("lg", [17, 20, 21])
+def test_ntt_large_bls12_381(gpu_ctx, oracle, lg):
+    """The second field (the `fft` crate's BLS12-381 Fr) at two- and three-pass sizes, incl. the 2^10-point sub-NTTs of 2^20 (ten lazy stages: the
+    value head-room of nine limbs is 70 r for this field, against 128 r for Pallas): forward, inverse and coset transforms against the oracle
+    (the synthetic values are below 2^254 < r_BLS: valid residues of this field too)."""
+    x = oracle.synth_column(81, 7, 0, 1 << lg)
+    y = gpu_ctx.fft(x, field=BLS12_381_FR)
+    assert (y == oracle.ntt(1, x)).all()
+    assert (gpu_ctx.ifft(y, field=BLS12_381_FR) == oracle.ntt(1, y, inverse=True)).all()
+    g = oracle.from_u64(7, 1)
+    assert (gpu_ctx.fft(x, field=BLS12_381_FR, coset=g) == oracle.ntt(1, x, coset=g)).all()
+
+
 def test_synthetic_generator(gpu_ctx, oracle):
     import ctypes as C
     import torch
