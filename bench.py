@@ -37,6 +37,7 @@ LOG_BLOWUP = 3
 SCHEDULE = [16, 16, 8]
 SEED_Z = 0xDEEFBAAD
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+STEP_COSET, STEP_Z = 5, 0xC0FFEE   # LDE coset shift (generator of Pallas Fr), fixed DEEP point of the kernels-only step
 MFMA_I8_PEAK_MACS = 2.5e15      # dense int8 MAC/s: twice the bf16 rate (MI355X_MICROARCH.md: about 2.5 PFLOP/s bf16 dense = 1.25 PMAC/s)
 FR_MULTS_T17, FR_MULTS_T9 = 21408, 5904   # reference-dense Fr-mults per permutation
 P_PALLAS = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
@@ -61,6 +62,54 @@ def leaf_kernel_macs():
     valu = (rf - 2) * full_valu + last + round0 + rp * part
     mfma = (rf - 2) * t * 64 * (t * 32)
     return valu, mfma
+
+
+def make_single_gpu_step(ctx, cols, log_n, dev):
+    """The N = 1 step of this bench as a closure over device-resident trace columns `cols` (four [2^log_n, 4] int64 tensors):
+    LDE of the four columns to 2^(log_n+3) points on the coset 5*<w>, DEEP-ALI merge at the fixed point z = 0xC0FFEE
+    (crates/deep_ali/src/lib.rs:48-105), fri_build_transcript with [16,16,8] (crates/deep_ali/src/fri.rs:231-312).  Returns the L+1
+    layer roots (Montgomery limbs).  tests/test_gpu_r3_step.py runs exactly this function against the oracle-generated golden roots."""
+    import numpy as np
+    import torch
+    from stark_mlwe_amd.api import _ptr, PALLAS_FR
+    lib = ctx.lib
+    N = 1 << (log_n + LOG_BLOWUP)
+    L = len(SCHEDULE)
+    sched = np.ascontiguousarray(SCHEDULE, dtype=np.uint64)
+    ext = [torch.empty((N, 4), dtype=torch.int64, device=dev) for _ in range(4)]
+    f0 = torch.empty((N, 4), dtype=torch.int64, device=dev)
+    omega = _root_of_unity_pallas(log_n + LOG_BLOWUP)
+    coset = _mont_small(STEP_COSET)
+    z = _mont_small(STEP_Z)         # fixed out-of-domain point for the kernels-only step (z^N != 1 checked by the library)
+
+    def step():
+        for c in range(4):   # LDE: interpolate on <w_n>, evaluate on 5*<w_N>
+            ctx._chk(lib.stark_lde_dev(ctx.h, PALLAS_FR, C.c_void_p(cols[c].data_ptr()), log_n, LOG_BLOWUP, _ptr(coset), C.c_void_p(ext[c].data_ptr())))
+        ctx._chk(lib.stark_ali_merge_dev(ctx.h, *[C.c_void_p(e.data_ptr()) for e in ext], None, None, _ptr(omega), _ptr(z), N, C.c_void_p(f0.data_ptr()), None))
+        st = C.c_void_p()
+        ctx._chk(lib.stark_fri_build_dev(ctx.h, C.c_void_p(f0.data_ptr()), N, _ptr(sched), L, SEED_Z, C.byref(st)))
+        roots = []
+        for l in range(L + 1):
+            r = np.zeros(4, np.uint64); ctx._chk(lib.stark_fri_layer_root(st, l, _ptr(r))); roots.append(r)
+        ctx._chk(lib.stark_fri_state_free(st))
+        return roots
+    return step
+
+
+def roots_hex(roots):
+    return ["".join(f"{int(x):016x}" for x in r[::-1]) for r in roots]
+
+
+def golden_step_roots(log_n, seed):
+    """Roots the CPU oracle produced ONCE for this step (tools/gen_golden.py step:K -> tests/golden/step_roots_kK.json), or None when
+    no golden exists for this size / seed.  A committed data file: the oracle itself is not touched here."""
+    path = os.path.join(ROOT, "tests", "golden", f"step_roots_k{log_n}.json")
+    if not os.path.exists(path):
+        return None
+    g = json.load(open(path))
+    if g.get("synth_seed") != seed or g.get("schedule") != SCHEDULE or g.get("seed_z") != SEED_Z or g.get("log_blowup") != LOG_BLOWUP or g.get("coset") != STEP_COSET or g.get("z") != STEP_Z:
+        return None
+    return g["roots"]
 
 
 def main():
@@ -118,25 +167,11 @@ def main():
     cols = [dbuf(n) for _ in range(4)]
     for c in range(4):
         ctx._chk(lib.stark_synth_column_dev(ctx.h, seed, c, rank * n, n, C.c_void_p(cols[c].data_ptr())))
-    coset = _mont_small(5)           # multiplicative generator of Pallas Fr as the LDE coset shift
-    z = _mont_small(0xC0FFEE)        # fixed out-of-domain point for the kernels-only step (z^N != 1 checked by the library)
+    coset = _mont_small(STEP_COSET)  # multiplicative generator of Pallas Fr as the LDE coset shift
+    z = _mont_small(STEP_Z)          # fixed out-of-domain point for the kernels-only step (z^N != 1 checked by the library)
 
     if world == 1:
-        ext = [dbuf(N) for _ in range(4)]
-        f0 = dbuf(N)
-        omega = _root_of_unity_pallas(log_n + LOG_BLOWUP)
-
-        def step():
-            for c in range(4):   # LDE: interpolate on <w_n>, evaluate on 5*<w_N>
-                ctx._chk(lib.stark_lde_dev(ctx.h, PALLAS_FR, C.c_void_p(cols[c].data_ptr()), log_n, LOG_BLOWUP, _ptr(coset), C.c_void_p(ext[c].data_ptr())))
-            ctx._chk(lib.stark_ali_merge_dev(ctx.h, *[C.c_void_p(e.data_ptr()) for e in ext], None, None, _ptr(omega), _ptr(z), N, C.c_void_p(f0.data_ptr()), None))
-            st = C.c_void_p()
-            ctx._chk(lib.stark_fri_build_dev(ctx.h, C.c_void_p(f0.data_ptr()), N, _ptr(sched), L, SEED_Z, C.byref(st)))
-            roots = []
-            for l in range(L + 1):
-                r = np.zeros(4, np.uint64); ctx._chk(lib.stark_fri_layer_root(st, l, _ptr(r))); roots.append(r)
-            ctx._chk(lib.stark_fri_state_free(st))
-            return roots
+        step = make_single_gpu_step(ctx, cols, log_n, dev)
         sharding = "one GPU holds the whole trace"
     else:
         from stark_mlwe_amd import dist as sd
@@ -193,8 +228,11 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"one 2^{log_n + (world.bit_length() - 1)}-row trace x 4 columns (2^{log_n} rows per GPU), blowup 8: LDE (iNTT + coset NTT) + DEEP-ALI merge + FRI folds + Poseidon leaf hashes + Poseidon-Merkle trees (schedule [16,16,8]), kernels only",
                    "log_trace_per_gpu": log_n, "log_blowup": LOG_BLOWUP, "schedule": SCHEDULE, "field": "pallas_fr", "sharding": sharding},
-        "roots": ["".join(f"{int(x):016x}" for x in r[::-1]) for r in roots],
+        "roots": roots_hex(roots),
     }
+    gold = golden_step_roots(log_n, seed) if world == 1 else None
+    # True / False against the committed oracle golden of exactly this step; null when no golden exists for this size, seed or N
+    out["roots_match_golden"] = None if gold is None else (out["roots"] == gold)
     if args.steps_only:
         if rank == 0:
             print(json.dumps(out), flush=True)

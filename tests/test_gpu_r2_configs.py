@@ -48,9 +48,9 @@ def test_end_to_end_prove_matches_oracle_golden(gpu_ctx, k, r):
     assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
 
 
-@pytest.mark.skipif(os.environ.get("STARK_LONG_TESTS") != "1", reason="2.6 GPU-minutes (155 s of serial column sponge): run with STARK_LONG_TESTS=1; the recorded run is profiles/r02_prove_2pow24_end_to_end.json")
 def test_end_to_end_prove_2pow24_matches_oracle_golden(gpu_ctx):
-    """north_star's target size on ONE GPU: `stark_deep_fri_prove_dev` of a 2^24-row trace (r = 40, [16,16,8]) from (a, s, e, t), proof
+    """(In the default `-m gpu` selection since round 3: about 2.5 GPU-minutes, almost all of it the serial column sponges.)
+    north_star's target size on ONE GPU: `stark_deep_fri_prove_dev` of a 2^24-row trace (r = 40, [16,16,8]) from (a, s, e, t), proof
     bytes against the golden the CPU oracle produced (tests/golden/proof_k24_r40.json, tools/gen_golden.py 24:40 — about two hours of 8 cores)."""
     path = os.path.join(GOLD, "proof_k24_r40.json")
     if not os.path.exists(path):
