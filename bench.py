@@ -177,19 +177,15 @@ def main():
         from stark_mlwe_amd import dist as sd
         if backend == "nccl" and os.environ.get("STARK_COMM", "lib") == "lib":
             # data-path collectives through the library's own RCCL communicator, on the shared stream (include/stark_mlwe.h
-            # stark_comm_*); torch.distributed only carried the unique id and brackets the timed region.  Should the library
-            # communicator fail to come up on ANY rank, every rank falls back to torch.distributed's RCCL (same exchanges).
-            lib_comm, ok = None, 1
-            try:
-                lib_comm = sd.LibComm(ctx, rank, world)
-            except Exception as ex:   # noqa: BLE001
-                ok = 0; sys.stderr.write(f"[bench] rank {rank}: library communicator unavailable ({ex!r}); falling back to torch.distributed\n")
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            # stark_comm_*); torch.distributed only carried the unique id and brackets the timed region.
+            # Agree FIRST on whether every rank can bind RCCL (a local probe), then enter the collective init together: a rank that
+            # failed inside LibComm() while its peers already sat in ncclCommInitRank would hang the job.
+            flag = torch.tensor([1 if lib.stark_comm_available(None) == 0 else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                sd.set_comm(lib_comm)
-            elif lib_comm is not None:
-                lib_comm.close()
+                sd.set_comm(sd.LibComm(ctx, rank, world))
+            elif rank == 0:
+                sys.stderr.write("[bench] library communicator unavailable on some rank; every rank uses torch.distributed's RCCL (same exchanges)\n")
         job = sd.ShardedTrace(sd.HipProvider(ctx, device=dev), log_n + (world.bit_length() - 1), LOG_BLOWUP, SCHEDULE, SEED_Z, coset, z)
 
         def step():

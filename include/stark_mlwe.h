@@ -299,6 +299,11 @@ int32_t stark_interleave_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* ds
  * the context's stream (no host synchronisation) and must be made by all ranks in the same order.  Without a usable RCCL the
  * calls fail with STARK_ERR_RCCL; nothing else in the library depends on it. */
 #define STARK_COMM_ID_BYTES 128
+/* Local probe (dlopen + ncclGetVersion, no communication): STARK_OK when RCCL can be bound and reports the major version whose ABI this
+ * library was checked against, else STARK_ERR_RCCL; *version_code (may be NULL) = its NCCL_VERSION_CODE.  Ranks agree on the answer BEFORE any
+ * of them enters the collective stark_comm_init (a rank that cannot load RCCL must not leave its peers blocked in ncclCommInitRank).
+ * STATUS: the N > 1 paths of this section have not run on hardware yet (no multi-GPU node was available to the build). */
+int32_t stark_comm_available(int32_t* version_code);
 int32_t stark_comm_unique_id(uint8_t* id128);
 int32_t stark_comm_init(stark_ctx_t* ctx, int32_t nranks, int32_t rank, const uint8_t* id128);
 int32_t stark_comm_destroy(stark_ctx_t* ctx);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "stark_ntt_columns_coset_dev": (i32, [vp, i32, vp, sz, sz, sz, sz, vp]),
     "stark_permute3_dev": (i32, [vp, vp, vp, sz, sz, sz, i32, i32, i32]),
     "stark_interleave_dev": (i32, [vp, vp, vp, sz, sz, sz]),
+    "stark_comm_available": (i32, [C.POINTER(i32)]),
     "stark_comm_unique_id": (i32, [vp]),
     "stark_comm_init": (i32, [vp, i32, i32, vp]),
     "stark_comm_destroy": (i32, [vp]),

@@ -25,8 +25,13 @@ typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;              // ncclSuccess == 0
 enum { NCCL_INT8 = 0, NCCL_UINT8 = 1, NCCL_UINT64 = 5 };   // ncclDataType_t
 enum { NCCL_SUM = 0 };                                      // ncclRedOp_t
+// The ten entry points below were checked against rccl.h of ROCm 7.2 (NCCL_VERSION_CODE 22707: ncclUniqueId = 128 opaque bytes passed
+// by value, ncclInt8 = 0, ncclUint8 = 1, ncclUint64 = 5, ncclSum = 0).  These have been stable through NCCL 2.x; a library that
+// reports another major version is refused at load time rather than trusted (stark_comm_* then return STARK_ERR_RCCL).
+constexpr int RCCL_MAJOR_CHECKED = 2;
 struct Rccl {
-    void* h = nullptr; bool tried = false;
+    void* h = nullptr; bool tried = false; int version = 0;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -50,7 +55,9 @@ struct Rccl {
         STARK_SYM(GetUniqueId, "ncclGetUniqueId") STARK_SYM(CommInitRank, "ncclCommInitRank") STARK_SYM(CommDestroy, "ncclCommDestroy")
         STARK_SYM(GetErrorString, "ncclGetErrorString") STARK_SYM(GroupStart, "ncclGroupStart") STARK_SYM(GroupEnd, "ncclGroupEnd")
         STARK_SYM(Send, "ncclSend") STARK_SYM(Recv, "ncclRecv") STARK_SYM(AllGather, "ncclAllGather") STARK_SYM(AllReduce, "ncclAllReduce")
+        STARK_SYM(GetVersion, "ncclGetVersion")
 #undef STARK_SYM
+        if (GetVersion(&version) != 0 || version / 10000 != RCCL_MAJOR_CHECKED) { h = nullptr; return false; }   // NCCL_VERSION_CODE = major*10000 + minor*100 + patch
         return true;
     }
 };
@@ -66,6 +73,13 @@ namespace stark { void comm_destroy(stark_ctx* ctx) { if (ctx->comm) { if (ctx->
 
 extern "C" {
 
+// Can this process bind RCCL?  Purely local (dlopen + ncclGetVersion): every rank calls it and the ranks agree on the answer BEFORE any of
+// them enters the collective stark_comm_init — a rank that cannot load RCCL must not leave its peers blocked inside ncclCommInitRank.
+int32_t stark_comm_available(int32_t* version_code) {
+    const bool ok = g_rccl.load();
+    if (version_code) *version_code = g_rccl.version;
+    return ok ? STARK_OK : STARK_ERR_RCCL;
+}
 int32_t stark_comm_unique_id(uint8_t* id128) {
     if (!id128) return STARK_ERR_INVALID_ARG;
     if (!g_rccl.load()) return STARK_ERR_RCCL;

@@ -122,26 +122,44 @@ class LibComm:
     def _p(t):
         return C.c_void_p(t.data_ptr())
 
+    # Same stream discipline as HipProvider._run (include/stark_mlwe.h "Stream rule"): the collectives run on the CONTEXT's
+    # stream while their tensors are produced and consumed by torch on ITS current stream.  One stream orders both only when the
+    # two are the same (bench.py's shared stream; Context(stream=None) with torch on the default stream); a STREAM_PRIVATE context,
+    # or torch moved to another stream, needs the explicit bracket — otherwise RCCL reads inputs that are not written yet and the
+    # consumer reads results that are not reduced yet.
+    def _shared(self, dev):
+        if self.ctx.private_stream:
+            return False
+        return self.ctx.stream_handle == torch.cuda.current_stream(dev).cuda_stream
+
+    def _run(self, dev, fn, *args):
+        shared = self._shared(dev)
+        if not shared:
+            torch.cuda.current_stream(dev).synchronize()
+        self.ctx._chk(fn(*args))
+        if not shared:
+            self.ctx.sync()
+
     def all_to_all(self, send):
         send = send.contiguous(); recv = torch.empty_like(send)
-        self.ctx._chk(self.lib.stark_comm_all_to_all_dev(self.ctx.h, self._p(send), self._p(recv), send.numel() * send.element_size() // self.W))
+        self._run(send.device, self.lib.stark_comm_all_to_all_dev, self.ctx.h, self._p(send), self._p(recv), send.numel() * send.element_size() // self.W)
         return recv
 
     def all_gather(self, x):
         dev = x if x.is_cuda else x.cuda()
         dev = dev.contiguous(); out = torch.empty((self.W * dev.shape[0],) + tuple(dev.shape[1:]), dtype=dev.dtype, device=dev.device)
-        self.ctx._chk(self.lib.stark_comm_all_gather_dev(self.ctx.h, self._p(dev), self._p(out), dev.numel() * dev.element_size()))
+        self._run(dev.device, self.lib.stark_comm_all_gather_dev, self.ctx.h, self._p(dev), self._p(out), dev.numel() * dev.element_size())
         return out if x.is_cuda else out.cpu()
 
     def all_reduce_sum(self, t):
         d = (t if t.is_cuda else t.cuda()).contiguous().clone()
-        self.ctx._chk(self.lib.stark_comm_all_reduce_u64_dev(self.ctx.h, self._p(d), self._p(d), d.numel() * d.element_size() // 8))
+        self._run(d.device, self.lib.stark_comm_all_reduce_u64_dev, self.ctx.h, self._p(d), self._p(d), d.numel() * d.element_size() // 8)
         return d if t.is_cuda else d.cpu()
 
     def gather_to(self, x, dst):
         x = x.contiguous()
         out = torch.empty((self.W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) if self.rank == dst else None
-        self.ctx._chk(self.lib.stark_comm_gather_dev(self.ctx.h, self._p(x), None if out is None else self._p(out), x.numel() * x.element_size(), dst))
+        self._run(x.device, self.lib.stark_comm_gather_dev, self.ctx.h, self._p(x), None if out is None else self._p(out), x.numel() * x.element_size(), dst)
         return out
 
     def close(self):

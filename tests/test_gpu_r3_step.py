@@ -31,3 +31,34 @@ def test_bench_step_roots_match_oracle_golden(gpu_ctx, k):
     step = bench.make_single_gpu_step(gpu_ctx, cols, k, dev)
     assert bench.roots_hex(step()) == gold["roots"]
     assert bench.roots_hex(step()) == gold["roots"]          # a second pass over the same buffers (what the timed loop does)
+
+
+def test_library_communicator_on_private_stream_context_is_bracketed():
+    """LibComm enqueues on the CONTEXT's stream while torch produces / consumes its tensors on torch's current
+    stream.  With a STARK_STREAM_PRIVATE context nothing orders the two, so LibComm must bracket every call like HipProvider._run
+    does.  A long torch-side producer (a chain of elementwise kernels) right before each collective makes a missing bracket visible:
+    the collective would read the buffer before the producer has finished."""
+    import torch
+    from stark_mlwe_amd import dist as sd
+    from stark_mlwe_amd.api import Context, STREAM_PRIVATE
+    ctx = Context(0, STREAM_PRIVATE)
+    try:
+        assert ctx.private_stream
+        assert ctx.lib.stark_comm_available(None) == 0
+        comm = sd.LibComm(ctx, 0, 1)
+        try:
+            assert not comm._shared(torch.device("cuda", 0))
+            for it in range(3):
+                x = torch.zeros((1 << 20, 4), dtype=torch.int64, device="cuda")
+                for k in range(40):                      # producer still running on torch's stream when the collective is issued
+                    x += 1
+                want = torch.full_like(x, 40)
+                assert bool((comm.all_to_all(x.view(1, -1, 4)).view(-1, 4) == want).all())
+                assert bool((comm.all_gather(x) == want).all())
+                assert bool((comm.all_reduce_sum(x) == want).all())
+                assert bool((comm.all_reduce_sum(x).cpu() == want.cpu()).all())          # consumer-side: the .cpu() copy runs on torch's stream
+                assert bool((comm.gather_to(x, 0) == want).all())
+        finally:
+            comm.close()
+    finally:
+        ctx.close()
