@@ -183,6 +183,14 @@ int32_t stark_deep_fri_prove(stark_ctx_t* ctx, const uint64_t* a, const uint64_t
                              size_t n0, const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out);
 int32_t stark_deep_fri_prove_dev(stark_ctx_t* ctx, const uint64_t* a, const uint64_t* s, const uint64_t* e, const uint64_t* t, const uint64_t* f0,
                                  size_t n0, const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out);
+/* `batch` independent traces of n0 rows each, one proof per trace (the reference's bench proves one trace after another,
+ * channel/benches/end_to_end.rs:229-309).  a, s, e, t: HOST arrays of `batch` DEVICE pointers; out: host array of `batch` proof handles
+ * (all NULL on failure).  The serial column sponges of build_f0 (fri.rs:548-557) bound a single prove and keep four waves of the chip
+ * busy; the 4 * batch chains of a batch are independent and run in ONE launch, so the stage costs what it costs for one trace.
+ * Every proof is byte-identical to stark_deep_fri_prove_dev on that trace alone.  stage_ms(0) of each proof = the shared sponge stage
+ * of the whole batch + that trace's merge. */
+int32_t stark_deep_fri_prove_batch_dev(stark_ctx_t* ctx, size_t batch, const uint64_t* const* a, const uint64_t* const* s, const uint64_t* const* e, const uint64_t* const* t,
+                                       size_t n0, const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out);
 size_t  stark_proof_len(stark_proof_t* p);
 int32_t stark_proof_bytes(stark_proof_t* p, uint8_t* out);
 size_t  stark_proof_size_estimate(stark_proof_t* p);                /* deep_fri_proof_size_bytes, fri.rs:764-805 */

@@ -276,6 +276,22 @@ pub mod fri {
         unsafe { stark_proof_free(raw); }
         (bytes, est)
     }
+    /// The bench loop of `channel/benches/end_to_end.rs:229-309` proves one trace after another; `traces[p] = (a, s, e, t)` as DEVICE
+    /// pointers of independent n0-row traces are proven in one call: the 4 * B serial column sponges of `build_f0` (fri.rs:548-557) run
+    /// concurrently, every proof is byte-identical to `deep_fri_prove` of that trace alone.
+    pub unsafe fn deep_fri_prove_batch_dev(ctx: &Ctx, traces: &[[*const u64; 4]], n0: usize, schedule: &[usize], r: usize, seed_z: u64) -> Vec<(Vec<u8>, usize)> {
+        let col = |c: usize| traces.iter().map(|t| t[c]).collect::<Vec<_>>();
+        let (a, s, e, t) = (col(0), col(1), col(2), col(3));
+        let mut raw: Vec<*mut stark_proof_t> = vec![ptr::null_mut(); traces.len()];
+        ctx.chk(stark_deep_fri_prove_batch_dev(ctx.raw, traces.len(), a.as_ptr(), s.as_ptr(), e.as_ptr(), t.as_ptr(), n0, schedule.as_ptr(), schedule.len(), r, seed_z, raw.as_mut_ptr()));
+        raw.into_iter().map(|h| {
+            let mut bytes = vec![0u8; stark_proof_len(h)];
+            ctx.chk(stark_proof_bytes(h, bytes.as_mut_ptr()));
+            let est = stark_proof_size_estimate(h);
+            stark_proof_free(h);
+            (bytes, est)
+        }).collect()
+    }
     /// `pub fn deep_fri_verify(params: &DeepFriParams, proof: &DeepFriProof) -> bool` — fri.rs:643-762, over the canonical bytes.
     pub fn deep_fri_verify(ctx: &Ctx, schedule: &[usize], r: usize, seed_z: u64, proof_bytes: &[u8]) -> bool {
         let mut ok = 0i32;

@@ -84,6 +84,7 @@ SIGNATURES = {
     "stark_build_f0_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp]),
     "stark_deep_fri_prove": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, sz, sz, u64, vpp]),
     "stark_deep_fri_prove_dev": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, sz, sz, u64, vpp]),
+    "stark_deep_fri_prove_batch_dev": (i32, [vp, sz, vp, vp, vp, vp, sz, vp, sz, sz, u64, vp]),
     "stark_proof_len": (sz, [vp]),
     "stark_proof_bytes": (i32, [vp, vp]),
     "stark_proof_size_estimate": (sz, [vp]),

@@ -433,6 +433,25 @@ class Context:
             self.lib.stark_proof_free(h)
         return bytes(buf), est, ms
 
+    def deep_fri_prove_batch_dev(self, traces, n0, params: DeepFriParams):
+        """`traces`: list of (a, s, e, t) DEVICE pointers (ints) of independent n0-row traces -> list of (proof bytes, size estimate, stage ms),
+        each equal to deep_fri_prove of that trace alone; the 4 * len(traces) serial column sponges run concurrently (stark_deep_fri_prove_batch_dev)."""
+        B = len(traces)
+        sch = np.ascontiguousarray(params.schedule, dtype=np.uint64)
+        cols = [(C.c_void_p * B)(*[int(tr[c]) for tr in traces]) for c in range(4)]
+        out = (C.c_void_p * B)()
+        self._chk(self.lib.stark_deep_fri_prove_batch_dev(self.h, B, cols[0], cols[1], cols[2], cols[3], n0, _ptr(sch), len(sch), params.r, params.seed_z, out))
+        res = []
+        for p in range(B):
+            h = C.c_void_p(out[p])
+            try:
+                ln = self.lib.stark_proof_len(h); buf = (C.c_uint8 * ln)()
+                self._chk(self.lib.stark_proof_bytes(h, buf))
+                res.append((bytes(buf), self.lib.stark_proof_size_estimate(h), [self.lib.stark_proof_stage_ms(h, i) for i in range(3)]))
+            finally:
+                self.lib.stark_proof_free(h)
+        return res
+
     def deep_fri_verify(self, params: DeepFriParams, proof: bytes) -> bool:
         """deep_fri_verify (fri.rs:643-762) on canonical proof bytes."""
         sch = np.ascontiguousarray(params.schedule, dtype=np.uint64)

@@ -163,12 +163,24 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
 // The four column sponges of DeepAliRealBuilder::build_f0 (fri.rs:551-554) as one launch of four blocks.
 int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev) {
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
-    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT");
+    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.batch = nullptr;
     for (int c = 0; c < 4; ++c) {
         fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tags[c], "out", &frame, &np, &ns));
         J.prefix[c] = frame; J.np[c] = np; J.suffix[c] = frame + np; J.ns[c] = ns; J.fields[c] = cols[c]; J.k[c] = n0;
     }
     hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(4), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out4_dev);
+    STARK_HIP(ctx, hipGetLastError());
+    return STARK_OK;
+}
+// The same for B independent traces: 4 * B chains, one block each, in one launch.  ptrs_dev[4 * p + c] = column c of trace p (device array of device pointers).
+int32_t tr_hash_columns_batch_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const* ptrs_dev, size_t batch, size_t n0, fr_t* out_dev) {
+    stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
+    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.batch = ptrs_dev;
+    for (int c = 0; c < 4; ++c) {
+        fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tags[c], "out", &frame, &np, &ns));
+        J.prefix[c] = frame; J.np[c] = np; J.suffix[c] = frame + np; J.ns[c] = ns; J.fields[c] = nullptr; J.k[c] = n0;
+    }
+    hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3((unsigned)(4 * batch)), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out_dev);
     STARK_HIP(ctx, hipGetLastError());
     return STARK_OK;
 }

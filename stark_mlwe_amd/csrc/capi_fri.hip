@@ -188,17 +188,22 @@ static int32_t ali_merge_dev_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, 
 }
 
 // ali_sample_z_beta_fs (fri.rs:511-533).
+static void ali_z_beta_from_fused(const fr_t& fused, size_t n0, const fr_t& roots_seed, fr_t* z, fr_t* beta);
 static int32_t ali_sample_z_beta(stark_ctx* ctx, const char* tag, size_t n0, const fr_t& roots_seed, fr_t* z, fr_t* beta) {
     fr_t fused; STARK_TRY(tr_hash_host1(ctx, tag, {roots_seed, host::h_u64(n0)}, &fused));
+    ali_z_beta_from_fused(fused, n0, roots_seed, z, beta); return STARK_OK;
+}
+// the RNG part of ali_sample_z_beta_fs (fri.rs:516-532): beta, then the first candidate outside H
+static void ali_z_beta_from_fused(const fr_t& fused, size_t n0, const fr_t& roots_seed, fr_t* z, fr_t* beta) {
     uint8_t seed[32]; host::h_to_bytes_le(fused, seed); host::ChaCha12Rng rng(seed);
     *beta = host::h_u64(rng.next_u64());
     const fr_t one = host::h_one();
     for (size_t tries = 0;;) {
         fr_t cand = host::h_u64(rng.next_u64());
-        if (!fr_is_zero(cand) && !fr_eq(fr_pow_u64<PallasFr>(cand, n0), one)) { *z = cand; return STARK_OK; }
+        if (!fr_is_zero(cand) && !fr_eq(fr_pow_u64<PallasFr>(cand, n0), one)) { *z = cand; return; }
         if (++tries >= 1000) {
             fr_t fb = host::h_add(roots_seed, host::h_u64(17));
-            *z = !fr_eq(fr_pow_u64<PallasFr>(fb, n0), one) ? fb : host::h_u64(19); return STARK_OK;
+            *z = !fr_eq(fr_pow_u64<PallasFr>(fb, n0), one) ? fb : host::h_u64(19); return;
         }
     }
 }
@@ -330,6 +335,65 @@ static int32_t prove_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, const fr
     *out = P; return STARK_OK;
 }
 
+// B independent proofs of equal shape (stark_deep_fri_prove_batch_dev).  What bounds one prove is the serial column sponge of build_f0
+// (fri.rs:548-557: n0/16 dependent permutations per column, one wave each): four waves of the chip are busy for 99 % of the time.  The chains of
+// different traces are independent, so all 4 * B of them run in ONE launch; the two Fiat-Shamir hashes per trace (ALI/seed, ALI/DEEP) are
+// one launch each for the whole batch; merge, fri_build and the query phase then run trace after trace on the context's stream.
+// Every proof is byte-for-byte what stark_deep_fri_prove_dev returns for that trace alone.
+static int32_t prove_batch_impl(stark_ctx* ctx, size_t B, const uint64_t* const* a, const uint64_t* const* s, const uint64_t* const* e, const uint64_t* const* t, size_t n0,
+                                const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof** out) {
+    if (!is_pow2(n0)) return ctx->fail(STARK_ERR_INVALID_ARG, "n0 must be a power of two (radix-2 domain)");
+    if (n0 <= 1) return ctx->fail(STARK_ERR_INVALID_ARG, "n0 > 1");
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_of = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+    for (size_t p = 0; p < B; ++p) out[p] = nullptr;
+    auto t0 = now();
+    // (1) all column digests: 4 * B serial sponges, concurrently
+    std::vector<const fr_t*> ptrs(4 * B);
+    for (size_t p = 0; p < B; ++p) { ptrs[4 * p] = as_fr(a[p]); ptrs[4 * p + 1] = as_fr(s[p]); ptrs[4 * p + 2] = as_fr(e[p]); ptrs[4 * p + 3] = as_fr(t[p]); }
+    DevBuf dptr, dig, seeds_in, seeds, deep_in, fused;
+    STARK_HIP(ctx, dptr.alloc(ctx, ptrs.size() * sizeof(void*))); STARK_HIP(ctx, dig.alloc(ctx, 4 * B * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(dptr.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    const char* tags[4] = {"ALI/A", "ALI/S", "ALI/E", "ALI/T"};
+    STARK_TRY(tr_hash_columns_batch_dev(ctx, tags, (const fr_t* const*)dptr.p, B, n0, dig.fr()));
+    std::vector<fr_t> h(4 * B);
+    STARK_HIP(ctx, hipMemcpyAsync(h.data(), dig.p, 4 * B * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (2) seed_f = H("ALI/seed", [h_a, h_s, h_e, h_t, n0]) and the fused hash of ali_sample_z_beta_fs, one launch each for the batch (fri.rs:556-557, 511-515)
+    const fr_t n0f = host::h_u64(n0);
+    std::vector<fr_t> in5(5 * B); for (size_t p = 0; p < B; ++p) { for (int c = 0; c < 4; ++c) in5[5 * p + c] = h[4 * p + c]; in5[5 * p + 4] = n0f; }
+    STARK_HIP(ctx, seeds_in.alloc(ctx, in5.size() * sizeof(fr_t))); STARK_HIP(ctx, seeds.alloc(ctx, B * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(seeds_in.p, in5.data(), in5.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(tr_hash_dev(ctx, "ALI/seed", seeds_in.fr(), 5, B, seeds.fr()));
+    std::vector<fr_t> seed_f(B);
+    STARK_HIP(ctx, hipMemcpyAsync(seed_f.data(), seeds.p, B * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<fr_t> in2(2 * B); for (size_t p = 0; p < B; ++p) { in2[2 * p] = seed_f[p]; in2[2 * p + 1] = n0f; }
+    STARK_HIP(ctx, deep_in.alloc(ctx, in2.size() * sizeof(fr_t))); STARK_HIP(ctx, fused.alloc(ctx, B * sizeof(fr_t)));
+    STARK_HIP(ctx, hipMemcpyAsync(deep_in.p, in2.data(), in2.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    STARK_TRY(tr_hash_dev(ctx, "ALI/DEEP", deep_in.fr(), 2, B, fused.fr()));
+    std::vector<fr_t> fu(B);
+    STARK_HIP(ctx, hipMemcpyAsync(fu.data(), fused.p, B * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto t1 = now();
+    // (3) per trace: merge, commit phase, query phase
+    const fr_t omega = fr_root_of_unity<PallasFr>((unsigned)ilog2(n0));
+    DevBuf f0buf; if (f0buf.alloc(ctx, n0 * sizeof(fr_t)) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "f0");
+    auto bail = [&](int32_t rc) { for (size_t p = 0; p < B; ++p) if (out[p]) { delete out[p]; out[p] = nullptr; } return rc; };
+    for (size_t p = 0; p < B; ++p) {
+        auto u0 = now();
+        fr_t z, beta; ali_z_beta_from_fused(fu[p], n0, seed_f[p], &z, &beta);
+        { int32_t rc = ali_merge_dev_impl(ctx, as_fr(a[p]), as_fr(s[p]), as_fr(e[p]), as_fr(t[p]), nullptr, host::h_zero(), omega, z, n0, f0buf.fr(), nullptr); if (rc) return bail(rc); }
+        auto u1 = now();
+        stark_fri_state* S = nullptr; { int32_t rc = fri_build_impl(ctx, f0buf.fr(), n0, schedule, L, seed_z, &S); if (rc) return bail(rc); }
+        auto u2 = now();
+        stark_proof* P = new stark_proof();
+        { int32_t rc = prove_queries_encode(ctx, S, n0, r, P); delete S; if (rc) { delete P; return bail(rc); } }
+        auto u3 = now();
+        P->ms[0] = ms_of(t0, t1) + ms_of(u0, u1);      // the shared sponge stage (whole batch) + this trace's merge
+        P->ms[1] = ms_of(u1, u2); P->ms[2] = ms_of(u2, u3);
+        out[p] = P;
+    }
+    return STARK_OK;
+}
+
 extern "C" {
 
 int32_t stark_fri_sample_z(stark_ctx_t* ctx, stark_params_t* tp, uint64_t seed_z, size_t level, size_t domain_size, uint64_t* z4) {
@@ -422,6 +486,13 @@ int32_t stark_deep_fri_prove(stark_ctx_t* ctx, const uint64_t* a, const uint64_t
     DevBuf d[5]; const uint64_t* src[5] = {a, s, e, t, f0};
     for (int i = 0; i < 5; ++i) if ((i < 4 && !f0) || (i == 4 && f0)) { STARK_HIP(ctx, d[i].alloc(ctx, n0 * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(d[i].p, src[i], n0 * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
     return stark_deep_fri_prove_dev(ctx, (const uint64_t*)d[0].p, (const uint64_t*)d[1].p, (const uint64_t*)d[2].p, (const uint64_t*)d[3].p, f0 ? (const uint64_t*)d[4].p : nullptr, n0, schedule, L, r, seed_z, out);
+}
+int32_t stark_deep_fri_prove_batch_dev(stark_ctx_t* ctx, size_t batch, const uint64_t* const* a, const uint64_t* const* s, const uint64_t* const* e, const uint64_t* const* t, size_t n0,
+                                       const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof_t** out) {
+    if (!ctx || !out || !batch || !a || !s || !e || !t || (!schedule && L)) return STARK_ERR_INVALID_ARG;
+    for (size_t p = 0; p < batch; ++p) if (!a[p] || !s[p] || !e[p] || !t[p]) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    return prove_batch_impl(ctx, batch, a, s, e, t, n0, schedule, L, r, seed_z, out);
 }
 size_t stark_proof_len(stark_proof_t* p) { return p ? p->bytes.size() : 0; }
 int32_t stark_proof_bytes(stark_proof_t* p, uint8_t* out) { if (!p || !out) return STARK_ERR_INVALID_ARG; memcpy(out, p->bytes.data(), p->bytes.size()); return STARK_OK; }

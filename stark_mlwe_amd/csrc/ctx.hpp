@@ -127,6 +127,7 @@ int32_t hash_ds_scattered(stark_ctx* ctx, stark_params* p, int mode, size_t arit
                           const fr_t* in0, const fr_t* in1, size_t n_hashes, fr_t* out);
 int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev);
 int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev);
+int32_t tr_hash_columns_batch_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const* ptrs_dev, size_t batch, size_t n0, fr_t* out_dev);
 int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out);   // one hash, host in/out
 
 }  // namespace stark

@@ -264,13 +264,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 }
 
 // Up to 4 independent long sponges in ONE launch (one block each): the four column chains of build_f0.
-struct TrMultiJob { const fr_t* prefix[4]; int np[4]; const fr_t* suffix[4]; int ns[4]; const fr_t* fields[4]; size_t k[4]; fr_t cap; };
+// With `batch` set, block b hashes column b & 3 of trace b >> 2 (stark_deep_fri_prove_batch_dev: the 4 * B chains of B independent traces
+// in one launch — each is serial, together they fill the chip); its fields pointer comes from the device array batch[b].
+struct TrMultiJob { const fr_t* prefix[4]; int np[4]; const fr_t* suffix[4]; int ns[4]; const fr_t* fields[4]; size_t k[4]; fr_t cap; const fr_t* const* batch; };
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_coop_multi(PoseidonDev P, TrMultiJob J, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
     CoopLds L = coop_setup<17>(lds, P);
-    const int lane = threadIdx.x, b = blockIdx.x;
-    const fr_t* prefix = J.prefix[b]; const fr_t* suffix = J.suffix[b]; const fr_t* fields = J.fields[b];
-    const size_t np = J.np[b], kk = J.k[b], total = np + kk + (size_t)J.ns[b];
+    const int lane = threadIdx.x, b = blockIdx.x, c = J.batch ? (b & 3) : b;
+    const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : J.fields[c];
+    const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
     fr_t s = lane == 16 ? J.cap : fr_zero<PF>();
     auto fetch = [&](size_t base) -> fr_t {                                                // this lane's element of the rate block starting at `base`
         const size_t e = base + lane;

@@ -62,3 +62,47 @@ def test_library_communicator_on_private_stream_context_is_bracketed():
             comm.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("k,B", [(10, 5), (16, 16)])
+def test_batch_prove_equals_single_proves(gpu_ctx, oracle, k, B):
+    """stark_deep_fri_prove_batch_dev: B independent traces in one call (the reference's bench proves one after another,
+    channel/benches/end_to_end.rs:229-309).  Each proof is byte-equal to the single prove of its trace (and, at 2^10, to the
+    oracle's); B = 16 proves of 2^16 rows take at most 1.3 x the time of one (the 4 * B serial column sponges of
+    crates/deep_ali/src/fri.rs:548-557 run concurrently)."""
+    import time
+    import torch
+    from stark_mlwe_amd.api import DeepFriParams
+    n0, sched, r, seed_z = 1 << k, [16, 16, 8] if k >= 12 else [16, 8], 32 if k >= 12 else 8, 0xDEEFBAAD
+    prm = DeepFriParams(sched, r, seed_z)
+    traces, keep = [], []
+    for p in range(B):
+        cols = [torch.empty((n0, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+        for c in range(4):
+            gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, 0xBA7C4000 + 16 * k + p, c, 0, n0, C.c_void_p(cols[c].data_ptr())))
+        keep.append(cols); traces.append([c.data_ptr() for c in cols])
+    torch.cuda.synchronize()
+    sch = __import__("numpy").ascontiguousarray(sched, dtype="uint64")
+
+    def single(p):
+        h = C.c_void_p()
+        gpu_ctx._chk(gpu_ctx.lib.stark_deep_fri_prove_dev(gpu_ctx.h, *[C.c_void_p(x) for x in traces[p]], None, n0, sch.ctypes.data_as(C.c_void_p), len(sched), r, seed_z, C.byref(h)))
+        return gpu_ctx._proof_out(h)[0]
+    single(0)                                              # warm constants, plans and the pool
+    t0 = time.perf_counter(); one = single(0); t_one = time.perf_counter() - t0
+    gpu_ctx.deep_fri_prove_batch_dev(traces[:1], n0, prm)   # warm the batch path
+    t0 = time.perf_counter(); got = gpu_ctx.deep_fri_prove_batch_dev(traces, n0, prm); t_batch = time.perf_counter() - t0
+    assert len(got) == B and got[0][0] == one
+    for p in (range(B) if k <= 12 else (1, B // 2, B - 1)):
+        assert got[p][0] == single(p), f"trace {p}"
+    assert len({g[0] for g in got}) == B                    # different traces, different proofs
+    if k == 10:
+        host_cols = [[c.cpu().numpy().view("uint64") for c in cols] for cols in keep]
+        for p in range(B):
+            ref = oracle.deep_fri_prove(*host_cols[p], n0, sched, r, seed_z)
+            assert got[p][0] == ref.bytes(); ref.free()
+    if k == 16:
+        rec = {"log_n0": k, "batch": B, "one_prove_s": t_one, "batch_s": t_batch, "ratio": t_batch / t_one}
+        out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
+        json.dump(rec, open(os.path.join(out, "batch_prove.json"), "w"), indent=1)
+        assert t_batch <= 1.3 * t_one, rec
