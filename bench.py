@@ -290,6 +290,7 @@ def main():
             sections[f"prove_end_to_end_2^{args.e2e_log}"] = dict(prove(args.e2e_log, False), note="build_f0 = the four serial column sponges (fri.rs:548-557), n0/16 dependent permutations each, one wave per column")
         sections["prove_given_f0_2^20"] = dict(prove(20, True), note="deep_fri_prove stages after build_f0 on n0 = 2^20")
         sections["reference_bench"] = reference_bench(ctx, np, args.csv, world)
+        sections["reference_bench_presets"] = preset_bench(ctx, np, torch, dev, args.csv, world)
 
     if rank == 0:
         traffic = None
@@ -353,6 +354,59 @@ def reference_bench(ctx, np, csv_path, gpus):
                                                                                                    r["prove_elems_per_s"], gpus, r["build_f0_ms"], r["fri_build_ms"], r["queries_encode_ms"], r["published_proof_bytes"]))
     return {"rows": rows, "all_match_published": all(r["matches_published"] and r["verified"] for r in rows),
             "note": "reference published prove 1.85 s / verify 103 ms at k = 11 ... 57.1 s / 212 ms at k = 16 (Apple arm64, 1 thread; benchmarkdata.csv:2-7)"}
+
+
+# The reference bench's other schedules (channel/benches/end_to_end.rs:195-201) and the Criterion means its authors left under
+# target/criterion/e2e_mf_fri/{prove,verify}-<label>/<k>/new/estimates.json (Apple arm64, one thread), ms.
+PRESETS = [("mod16", [16, 16, 16, 16]), ("uni32x3", [32, 32, 32]), ("uni64x2x8", [64, 64, 8]), ("hi64_32_8", [64, 32, 8]), ("hi32_32_16", [32, 32, 16])]
+PUBLISHED_PRESET_MS = {("mod16", 16): (55906.8, 240.5), ("uni32x3", 15): (27146.9, 162.1), ("uni32x3", 16): (54165.2, 195.1), ("uni64x2x8", 15): (26999.7, 135.5),
+                       ("uni64x2x8", 16): (53552.6, 166.4), ("hi64_32_8", 14): (13454.9, 130.8), ("hi64_32_8", 15): (27069.2, 150.0), ("hi64_32_8", 16): (53520.7, 183.3),
+                       ("hi32_32_16", 14): (13647.6, 148.4), ("hi32_32_16", 15): (27093.2, 169.0), ("hi32_32_16", 16): (54904.8, 196.2)}
+
+
+def preset_bench(ctx, np, torch, dev, csv_path, gpus):
+    """deep_fri_prove / deep_fri_verify for the reference bench's presets other than "paper" at the sizes its authors measured (k_min .. 16):
+    layers of arity 32 / 64 (Poseidon widths t = 33 / 65).  Inputs: the synthetic trace (seed 0x5EED0000 + k) — the reference's seed chain for
+    these presets depends on how many ks its "paper" loop ran, which the repo does not record, and it published no proof sizes for them.
+    Per row: end-to-end prove from (a, s, e, t), the stages after build_f0 alone (`prove_given_f0_ms`), verify."""
+    from stark_mlwe_amd.api import _ptr
+    lib = ctx.lib
+    rows = []
+    for label, sched_l in PRESETS:
+        sch = np.ascontiguousarray(sched_l, dtype=np.uint64)
+        kmin = sum(int(m).bit_length() - 1 for m in sched_l)
+        for k in range(max(14, kmin), 17):
+            nk = 1 << k
+            cs = [torch.empty((nk, 4), dtype=torch.int64, device=dev) for _ in range(4)]
+            for c in range(4):
+                ctx._chk(lib.stark_synth_column_dev(ctx.h, 0x5EED0000 + k, c, 0, nk, C.c_void_p(cs[c].data_ptr())))
+            ptr = [C.c_void_p(x.data_ptr()) for x in cs]
+
+            def run(given_f0):
+                ph = C.c_void_p()
+                t0 = time.perf_counter()
+                ctx._chk(lib.stark_deep_fri_prove_dev(ctx.h, *([None] * 4 + [ptr[0]] if given_f0 else ptr + [None]), nk, _ptr(sch), len(sched_l), 32, SEED_Z, C.byref(ph)))
+                wall = (time.perf_counter() - t0) * 1e3
+                ms = [lib.stark_proof_stage_ms(ph, i) for i in range(3)]
+                proof, est = ctx._proof_out(ph)
+                return wall, ms, proof, est
+            run(True)                                    # warm this schedule's parameter sets (t = 33 / 65) and plans
+            wall_f0, ms_f0, _, _ = run(True)
+            wall, ms, proof, est = run(False)
+            prm = __import__("stark_mlwe_amd.api", fromlist=["DeepFriParams"]).DeepFriParams(sched_l, 32, SEED_Z)
+            t0 = time.perf_counter(); ok = ctx.deep_fri_verify(prm, proof); verify_ms = (time.perf_counter() - t0) * 1e3
+            pub = PUBLISHED_PRESET_MS.get((label, k), (None, None))
+            rows.append({"label": label, "k": k, "schedule": sched_l, "proof_bytes": est, "encoded_bytes": len(proof), "prove_s": wall / 1e3, "verify_ms": verify_ms, "verified": bool(ok),
+                         "build_f0_ms": ms[0], "fri_build_ms": ms[1], "queries_encode_ms": ms[2], "prove_given_f0_ms": wall_f0, "given_f0_fri_build_ms": ms_f0[1], "given_f0_queries_encode_ms": ms_f0[2],
+                         "prove_elems_per_s": nk / (wall / 1e3), "published_prove_ms": pub[0], "published_verify_ms": pub[1]})
+            del cs
+    if csv_path:
+        with open(csv_path, "a") as f:
+            for r in rows:
+                f.write("csv,%s,%d,[%s],%d,%.6f,%.3f,%.6f,,,,,%d,%.3f,%.3f,%.3f,\n" % (r["label"], r["k"], ",".join(str(m) for m in r["schedule"]), r["proof_bytes"], r["prove_s"], r["verify_ms"],
+                                                                                     r["prove_elems_per_s"], gpus, r["build_f0_ms"], r["fri_build_ms"], r["queries_encode_ms"]))
+    return {"rows": rows, "all_verified": all(r["verified"] for r in rows),
+            "note": "synthetic inputs; published_* = the reference authors' Criterion means (Apple arm64, 1 thread; SURVEY.md §6(b)); prove is bounded by the serial column sponges whatever the schedule, prove_given_f0_ms is what the schedule changes"}
 
 
 def _mont_small(x):

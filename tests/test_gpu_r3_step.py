@@ -106,3 +106,31 @@ def test_batch_prove_equals_single_proves(gpu_ctx, oracle, k, B):
         out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
         json.dump(rec, open(os.path.join(out, "batch_prove.json"), "w"), indent=1)
         assert t_batch <= 1.3 * t_one, rec
+
+
+PRESET_CASES = [("mod16", [16, 16, 16, 16], 16), ("uni32x3", [32, 32, 32], 15), ("uni64x2x8", [64, 64, 8], 15), ("hi64_32_8", [64, 32, 8], 14), ("hi32_32_16", [32, 32, 16], 14)]
+
+
+@pytest.mark.parametrize("label,sched,k", PRESET_CASES)
+def test_reference_bench_presets_match_oracle_golden(gpu_ctx, label, sched, k):
+    """The reference bench's schedules other than "paper" (channel/benches/end_to_end.rs:195-201: layers of arity 32 / 64, Poseidon widths
+    33 / 65) at the smallest size the reference ran them (k_min = sum log2 m): proof bytes from (a, s, e, t) equal the oracle's
+    (tests/golden/proof_k{k}_r32_{label}.json, tools/gen_golden.py preset:{label}:{k}), and the product's verifier accepts them."""
+    import hashlib
+    import numpy as np
+    import torch
+    from stark_mlwe_amd.api import DeepFriParams
+    path = os.path.join(GOLD, f"proof_k{k}_r32_{label}.json")
+    assert os.path.exists(path), f"{path} missing (tools/gen_golden.py preset:{label}:{k})"
+    gold = json.load(open(path))
+    assert gold["schedule"] == sched and gold["r"] == 32 and gold["log_n0"] == k
+    n0 = 1 << k
+    cols = [torch.empty((n0, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+    for c in range(4):
+        gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, gold["synth_seed"], c, 0, n0, C.c_void_p(cols[c].data_ptr())))
+    sch = np.ascontiguousarray(sched, dtype=np.uint64); h = C.c_void_p()
+    gpu_ctx._chk(gpu_ctx.lib.stark_deep_fri_prove_dev(gpu_ctx.h, *[C.c_void_p(c.data_ptr()) for c in cols], None, n0, sch.ctypes.data_as(C.c_void_p), len(sched), 32, gold["seed_z"], C.byref(h)))
+    proof, est = gpu_ctx._proof_out(h)
+    assert len(proof) == gold["proof_len"] and est == gold["size_estimate"]
+    assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
+    assert gpu_ctx.deep_fri_verify(DeepFriParams(sched, 32, gold["seed_z"]), proof)

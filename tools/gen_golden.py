@@ -19,6 +19,9 @@ Run ONCE in the build container (all host cores; k = 22 takes about a quarter of
 synthetic columns to 2^(K+3) points on the coset 5*<w> (oracle/ntt.hpp), DEEP-ALI merge at the fixed point z = 0xC0FFEE
 (oracle/fri.hpp, crates/deep_ali/src/lib.rs:48-105), fri_build_transcript with [16,16,8] (crates/deep_ali/src/fri.rs:231-312)
 -> tests/golden/step_roots_k{K}.json.  `step:20` is the bench size (about half an hour of all host cores).
+
+`preset:LABEL:K` records the proof of one of the reference bench's other schedules (channel/benches/end_to_end.rs:195-201) at 2^K rows, r = 32
+-> tests/golden/proof_k{K}_r32_{LABEL}.json (trees of arity 32 / 64 = Poseidon widths 33 / 65).
 """
 import hashlib
 import json
@@ -33,6 +36,7 @@ SCHEDULE = [16, 16, 8]
 SEED_Z = 0xDEEFBAAD
 
 
+PRESETS = {"paper": [16, 16, 8], "mod16": [16, 16, 16, 16], "uni32x3": [32, 32, 32], "uni64x2x8": [64, 64, 8], "hi64_32_8": [64, 32, 8], "hi32_32_16": [32, 32, 16]}
 P_PALLAS = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
 LOG_BLOWUP = 3
 STEP_Z = 0xC0FFEE
@@ -79,18 +83,21 @@ def main():
                 f.write("\n")
             print(path, rec["roots"], f"{rec['oracle_seconds']} s", flush=True)
             continue
+        schedule, label = SCHEDULE, None
+        if spec.startswith("preset:"):
+            _, label, kk = spec.split(":"); schedule = PRESETS[label]; spec = f"{kk}:32"
         k, r = (int(x) for x in spec.split(":"))
         n0 = 1 << k
         t0 = time.time()
         cols = [o.synth_column(0x5EED0000 + k, c, 0, n0) for c in range(4)]
-        pr = o.deep_fri_prove(cols[0], cols[1], cols[2], cols[3], n0, SCHEDULE, r, SEED_Z)
+        pr = o.deep_fri_prove(cols[0], cols[1], cols[2], cols[3], n0, schedule, r, SEED_Z)
         b = pr.bytes()
-        rec = {"log_n0": k, "r": r, "schedule": SCHEDULE, "seed_z": SEED_Z, "synth_seed": 0x5EED0000 + k,
+        rec = {"log_n0": k, "r": r, "schedule": schedule, "seed_z": SEED_Z, "synth_seed": 0x5EED0000 + k,
                "proof_len": len(b), "size_estimate": pr.size_estimate(), "sha256": hashlib.sha256(b).hexdigest(),
                "roots": ["".join(f"{int(x):016x}" for x in pr.root(l)[::-1]) for l in range(pr.num_layers())],
                "generator": "tools/gen_golden.py (oracle/fri.hpp deep_fri_prove, all host cores)", "oracle_seconds": round(time.time() - t0, 1)}
         pr.free()
-        path = os.path.join(ROOT, "tests", "golden", f"proof_k{k}_r{r}.json")
+        path = os.path.join(ROOT, "tests", "golden", f"proof_k{k}_r{r}.json" if label is None else f"proof_k{k}_r{r}_{label}.json")
         with open(path, "w") as f:
             json.dump(rec, f, indent=1)
             f.write("\n")
