@@ -296,6 +296,11 @@ int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, s
  *   stark_permute3_dev: dst (contiguous) = the [d0][d1][d2] array src with its axes permuted to (p0, p1, p2) — the layout
  *            changes on either side of an all-to-all (32-byte elements).
  *   stark_interleave_dev: dst[k*stride + offset] = src[k], k < n — the coset transforms of an LDE into natural order. */
+/*   stark_ntt_rows_coset_dev: first local phase of a forward COSET transform on the layout the inverse six-step transform leaves behind
+ *            (rows k1 = row0 .. row0+nrows of the [R][C] view c[k1 + R k'], C = 2^log_cols contiguous, R = 2^(log_n-log_cols)):
+ *            dst[i][m] = w_n^(k1 m) * sum_k' src[i][k'] shift^(k' R + k1) w_C^(k' m).  src is not modified (all cosets of an LDE start from it);
+ *            the second phase is a plain size-R transform over k1 after ONE exchange — no exchange between inverse and forward. */
+int32_t stark_ntt_rows_coset_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* src, uint64_t* dst, size_t nrows, size_t log_cols, size_t row0, size_t log_n, const uint64_t* shift4);
 int32_t stark_ntt_columns_coset_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, const uint64_t* shift4);
 int32_t stark_permute3_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t d0, size_t d1, size_t d2, int32_t p0, int32_t p1, int32_t p2);
 int32_t stark_interleave_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t n, size_t stride, size_t offset);

@@ -23,8 +23,11 @@ struct NttPlan {
     fr_t* tw_direct[2] = {nullptr, nullptr}; fr_t* coset_direct = nullptr;
     // power tables of coset shifts used by the multi-GPU column phase (a handful: the 2^log_blowup cosets of an LDE)
     std::vector<std::pair<fr_t, DevTable>> shift_tabs;
+    // plain (c0 = 1) power tables for the element-wise kernels of stark_ntt_rows_coset_dev: coset shifts, and w_N itself (key = one)
+    std::vector<std::pair<fr_t, DevTable>> plain_tabs;
     ~NttPlan() {
         for (auto& st : shift_tabs) { if (st.second.lo) (void)hipFree(st.second.lo); if (st.second.hi) (void)hipFree(st.second.hi); }
+        for (auto& st : plain_tabs) { if (st.second.lo) (void)hipFree(st.second.lo); if (st.second.hi) (void)hipFree(st.second.hi); }
         for (auto p : tw_direct) if (p) (void)hipFree(p);
         if (coset_direct) (void)hipFree(coset_direct);
         for (auto p : stage_tw) if (p) (void)hipFree(p);
@@ -181,8 +184,10 @@ static int32_t lde_run(stark_ctx* ctx, const fr_t* evals, int log_n, int log_blo
     fr_t one = fr_one<F>(); bool unit = !coset || fr_eq(*coset, one);
     // The zero padding is never written when the big transform has a strided first pass whose stride divides n: that pass reads
     // only the n coefficient rows and takes the rest as zero (NttPassArgs::nz_points).  Otherwise (tiny transforms) pad for real.
-    const int big = log_n + log_blowup; int first_b = big <= 10 ? big : (big <= 20 ? (big + 1) / 2 : (big + 2) / 3);
-    const bool skip = N > n && big > 10 && (big - first_b) <= log_n;
+    // (first-pass size taken from the plan itself, so that a retuned split can never leave out[n..N) unwritten AND unread-as-zero)
+    const int big = log_n + log_blowup;
+    NttPlan* bp = nullptr; STARK_TRY(get_plan<F>(ctx, big, false, &bp));
+    const bool skip = N > n && bp->P > 1 && (big - bp->log_b[0]) <= log_n;
     if (N > n && !skip) { hipLaunchKernelGGL(k_zero_fill<F>, dim3((unsigned)((N - n + 255) / 256)), dim3(256), 0, ctx->stream, out + n, N - n); STARK_HIP(ctx, hipGetLastError()); }
     return ntt_run<F>(ctx, out, big, 1, false, unit ? nullptr : coset, nullptr, skip ? log_n : -1);   // coefficients -> coset evaluations on the larger domain
 }
@@ -227,8 +232,51 @@ static int32_t columns_run(stark_ctx* ctx, fr_t* slab, int log_rows, uint64_t nc
     }
     return launch_strided<F>(ctx, A, (uint64_t)ncols << log_rows, slab, slab);
 }
+// Multi-GPU forward transform, first local phase, on the layout the inverse transform leaves behind (dist.py ShardedLde): rows k1 = row0 + i of the
+// [R][C] view c[k1 + R k'] (R = 2^(log_n - log_cols) rows in the whole vector, this rank holds nrows of them, each contiguous over k').
+//   dst[i][m] = w_n^(k1 m) * sum_k' src[i][k'] shift^(k' R + k1) w_C^(k' m)
+// i.e. coset pre-scale at the natural index, size-C transforms along the contiguous axis, inter-step twiddle.  The second phase is a plain size-R
+// transform over k1 after the exchange.  src is left untouched (the 2^log_blowup cosets of an LDE all start from the same coefficients).
+template <class F>
+static int32_t plain_table(stark_ctx* ctx, NttPlan* big, const fr_t& base, int log_n, PowTable* out) {
+    for (auto& st : big->plain_tabs) if (fr_eq(st.first, base)) { *out = st.second.view(); return STARK_OK; }
+    if (big->plain_tabs.size() >= 40) { STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); auto& old = big->plain_tabs.front(); (void)hipFree(old.second.lo); (void)hipFree(old.second.hi); big->plain_tabs.erase(big->plain_tabs.begin()); }
+    big->plain_tabs.push_back({base, DevTable()});
+    const int lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
+    STARK_TRY(fill_table<F>(ctx, base, fr_one<F>(), lo_bits, hi_bits, big->plain_tabs.back().second));
+    *out = big->plain_tabs.back().second.view(); return STARK_OK;
+}
+template <class F>
+static int32_t rows_coset_run(stark_ctx* ctx, const fr_t* src, fr_t* dst, uint64_t nrows, int log_cols, uint64_t row0, int log_n, const fr_t& shift) {
+    if (log_cols < 0 || log_cols > log_n || log_n > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "rows_coset: sizes");
+    const int log_rows = log_n - log_cols;
+    if (!nrows || row0 + nrows > (1ull << log_rows)) return ctx->fail(STARK_ERR_INVALID_ARG, "rows_coset: row range");
+    NttPlan* big = nullptr; STARK_TRY(get_plan<F>(ctx, log_n, false, &big));
+    PowTable tsh, troot;
+    STARK_TRY(plain_table<F>(ctx, big, shift, log_n, &tsh));
+    // w_N is stored under a key no coset can equal by accident only if it differs from every shift in use: the root of unity itself is a legal shift,
+    // and then the two tables are the same table — which is correct
+    STARK_TRY(plain_table<F>(ctx, big, fr_root_of_unity<F>((unsigned)log_n), log_n, &troot));
+    STARK_TRY(plain_table<F>(ctx, big, shift, log_n, &tsh));          // in case inserting w_N evicted it (the cache is a small FIFO)
+    const uint64_t tot = nrows << log_cols; const unsigned grid = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_rows_coset_pre<F>, dim3(grid), dim3(256), 0, ctx->stream, src, dst, tsh, nrows, log_cols, row0, log_rows);
+    STARK_HIP(ctx, hipGetLastError());
+    STARK_TRY(ntt_run<F>(ctx, dst, log_cols, nrows, false, nullptr, nullptr));
+    hipLaunchKernelGGL(k_rows_twiddle<F>, dim3(grid), dim3(256), 0, ctx->stream, dst, troot, nrows, log_cols, row0, log_n);
+    STARK_HIP(ctx, hipGetLastError());
+    return STARK_OK;
+}
+
 extern "C" {
 
+int32_t stark_ntt_rows_coset_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* src, uint64_t* dst, size_t nrows, size_t log_cols, size_t row0, size_t log_n, const uint64_t* shift4) {
+    if (!ctx || !src || !dst || !shift4 || src == dst) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const fr_t sh = load_fr(shift4);
+    if (field_id == STARK_FIELD_PALLAS_FR) return rows_coset_run<PallasFr>(ctx, as_fr(src), as_fr(dst), nrows, (int)log_cols, row0, (int)log_n, sh);
+    if (field_id == STARK_FIELD_BLS12_381_FR) return rows_coset_run<Bls12381Fr>(ctx, as_fr(src), as_fr(dst), nrows, (int)log_cols, row0, (int)log_n, sh);
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
 int32_t stark_ntt_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* data, size_t log_n, int32_t inverse, const uint64_t* coset4) {
     if (!ctx || !data) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));

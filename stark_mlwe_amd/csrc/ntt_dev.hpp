@@ -301,6 +301,26 @@ __global__ void k_fill_pow_direct(PowTable t, uint64_t n, fr_t* out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) stg(out + i, pow_lookup<F>(t, i));
 }
+// Multi-GPU forward transform fed by the inverse's transposed output (stark_ntt_rows_coset_dev): the slab holds rows k1 = row0 + i of the
+// [R][C] view c[k1 + R * k'] of a coefficient vector.
+//   pre : dst[i][k'] = src[i][k'] * shift^(k' * R + k1)        — the coset pre-scale x[j] * shift^j at the element's natural index j
+//   post: y[i][m]   *= w_n^(k1 * m)                             — the inter-step twiddle of the six-step split n = C x R
+// Plain Montgomery tables (c0 = 1), not the x32 tables of the tiled NTT passes.
+template <class F>
+__global__ void k_rows_coset_pre(const fr_t* __restrict__ src, fr_t* __restrict__ dst, PowTable shift, uint64_t nrows, int log_cols, uint64_t row0, int log_rows) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (nrows << log_cols)) return;
+    const uint64_t i = t >> log_cols, kp = t & ((1ull << log_cols) - 1);
+    stg(dst + t, fr_mul<F>(ldg(src + t), pow_lookup<F>(shift, (kp << log_rows) + row0 + i)));
+}
+template <class F>
+__global__ void k_rows_twiddle(fr_t* __restrict__ y, PowTable root, uint64_t nrows, int log_cols, uint64_t row0, int log_n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (nrows << log_cols)) return;
+    const uint64_t i = t >> log_cols, m = t & ((1ull << log_cols) - 1);
+    const uint64_t e = ((row0 + i) * m) & ((1ull << log_n) - 1);
+    if (e) stg(y + t, fr_mul<F>(ldg(y + t), pow_lookup<F>(root, e)));
+}
 template <class F>
 __global__ void k_zero_fill(fr_t* p, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

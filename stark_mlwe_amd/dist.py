@@ -180,8 +180,12 @@ def world():
     return _COMM.world()
 
 
+STATS = {"all_to_all": 0}          # exchanges issued through this module (tests and bench.py report the counted number, not a formula)
+
+
 def exchange_all_to_all(send: torch.Tensor) -> torch.Tensor:
     """send: [W, chunk...] — chunk q goes to rank q.  Returns recv with chunk p = what rank p sent here."""
+    STATS["all_to_all"] += 1
     return _COMM.all_to_all(send)
 
 
@@ -228,6 +232,10 @@ class HipProvider:
     def ntt_columns_coset(self, slab, log_rows, ncols, col0, log_n, shift4):
         self._run(self.lib.stark_ntt_columns_coset_dev, self.ctx.h, self.field, self._p(slab), log_rows, ncols, col0, log_n, _npp(shift4))
 
+    def ntt_rows_coset(self, src, out, nrows, log_cols, row0, log_n, shift4):
+        """First local phase of a forward coset transform on the inverse's transposed output (stark_ntt_rows_coset_dev): src -> out."""
+        self._run(self.lib.stark_ntt_rows_coset_dev, self.ctx.h, self.field, self._p(src), self._p(out), nrows, log_cols, row0, log_n, _npp(shift4))
+
     def permute3(self, src, dims, perm):
         """Contiguous [dims[perm[0]], dims[perm[1]], dims[perm[2]], 4] copy of the [d0][d1][d2] array `src` (hand-written pack kernel)."""
         out = torch.empty((dims[perm[0]] * dims[perm[1]] * dims[perm[2]], 4), dtype=torch.int64, device=src.device)
@@ -253,9 +261,11 @@ class HipProvider:
         """(device tensor [k, 4] copy of the last level, number of levels)."""
         nl = self.lib.stark_merkle_num_levels(h)
         k = self.lib.stark_merkle_level_len(h, nl - 1)
-        tmp = torch.empty((k, 4), dtype=torch.int64)
-        self._run(self.lib.stark_merkle_level, h, nl - 1, C.c_void_p(tmp.data_ptr()))   # a few digests: host hop is fine
-        return tmp.to(self.device), nl
+        out = torch.empty((k, 4), dtype=torch.int64, device=self.device)
+        src = self.lib.stark_merkle_level_dev(h, nl - 1)
+        # device-to-device on the context's stream (the pack kernel with stride 1 is a plain copy): the tree top never visits the host
+        self._run(self.lib.stark_interleave_dev, self.ctx.h, C.c_void_p(src), self._p(out), k, 1, 0)
+        return out, nl
 
     def merkle_free(self, h):
         self.lib.stark_merkle_free(h)
@@ -414,34 +424,50 @@ class DistNtt:
 class ShardedLde:
     """LDE of ONE column of n = 2^log_n evaluations (natural order, block-sharded: rank q holds [q*n/W, (q+1)*n/W)) to
     N = n * 2^log_blowup evaluations on shift * <w_N>, natural order, block-sharded again.
-        coefficients  c = iNTT_n(evals)                                   (six-step, one transpose)
+        coefficients  c = iNTT_n(evals)
         out[b*k + s]  = NTT_n(c[j] * (shift * w_N^s)^j)[k],  s < b = 2^log_blowup     (b coset transforms of size n: the zero
                                                                             padding of the definition is never materialised)
-    Every transform is a `DistNtt`; between them only layout changes (all-to-all + pack kernels)."""
+    FOUR all-to-alls per column, whatever the blow-up (view the vector as [R][C], R <= 1024):
+      1. natural row blocks -> column blocks [R][C/W]                      (the inverse's column phase needs whole columns)
+      2. the inverse transform's own transpose -> rows k1 of c[k1 + R k'], [R/W][C], coefficients
+         — this IS the input layout of a forward transform split the other way round (n = C x R): its first phase runs along the
+         contiguous k' axis of the same slab (`ntt_rows_coset`: coset pre-scale, size-C transforms, inter-step twiddle), so nothing
+         is exchanged between the inverse and the forward transforms;
+      3. ONE exchange for the first-phase outputs of all b cosets -> [b][C/W][R], then plain size-R transforms over k1;
+      4. ONE exchange of all b results into natural block order (the cosets are interleaved by the pack kernel on the way)."""
 
     def __init__(self, provider, log_n, log_blowup, shift_int=5, log_rows=None):
         self.p, self.log_n, self.lb = provider, log_n, log_blowup
         self.rank, self.W = world()
         self.inv = DistNtt(provider, log_n, log_rows, inverse=True)
-        self.fwd = DistNtt(provider, log_n, log_rows, inverse=False)
         fld = getattr(provider, "field", 0)
         P = _P[fld]
         wN = pow(_GEN[fld], (P - 1) >> (log_n + log_blowup), P)
         self.shifts = [_mont(shift_int * pow(wN, s_, P) % P, fld) for s_ in range(1 << log_blowup)]
         self.ninv = _mont(pow(1 << log_n, -1, P), fld)
-        self.n_all_to_all = 3 + 2 * (1 << log_blowup)
+        self.n_all_to_all = 4
+
+    def _perm(self, t, dims, perm):
+        return self.inv._perm(t, dims, perm)
 
     def __call__(self, block: torch.Tensor) -> torch.Tensor:
-        b = 1 << self.lb
-        coeff_rows = self.inv.forward(self.inv.from_natural_blocks(block), self.ninv)      # coefficients, transposed block order
-        coeff = self.inv.to_natural_blocks(coeff_rows)
-        slab0 = self.fwd.from_natural_blocks(coeff)                                        # input layout of the forward transforms
-        out = self.p.new(block.shape[0] * b)
+        b, W, inv = 1 << self.lb, self.W, self.inv
+        R, Cc, nrl, ncl = inv.R, inv.C, inv.nrl, inv.ncl
+        coeff = inv.forward(inv.from_natural_blocks(block), self.ninv)                     # exchanges 1, 2: [R/W][C] = c[k1 + R k'], k1 local
+        # first phase of every coset transform, local: P_s[k1][K1]
+        first = self.p.new(b * nrl * Cc)
         for s_ in range(b):
-            slab = slab0.clone() if s_ + 1 < b else slab0
-            y = self.fwd.to_natural_blocks(self.fwd.forward(slab, None, self.shifts[s_]))
-            self.p.interleave(out, y, b, s_)
-        return out
+            self.p.ntt_rows_coset(coeff, first[s_ * nrl * Cc:(s_ + 1) * nrl * Cc], nrl, self.log_n - inv.log_rows, self.rank * nrl, self.log_n, self.shifts[s_])
+        # exchange 3: K1 block q of every coset and local row goes to rank q
+        send = self._perm(first, (b * nrl, W, ncl), (1, 0, 2))                              # [dst q][s, k1 local][K1 local]
+        recv = exchange_all_to_all(send.view(W, -1, 4))                                    # [src p][s][k1 local][K1 local]
+        cols = self._perm(recv.view(-1, 4), (W, b, nrl * ncl), (1, 0, 2))                   # [s][p][k1 local][K1 local] = [s][k1][K1 local]
+        rows = self._perm(cols, (b, R, ncl), (0, 2, 1))                                     # [s][K1 local][k1]
+        self.p.ntt_rows(rows, b * ncl, inv.log_rows, False)                                 # second phase: Y_s[K1 + C K2], [s][K1 local][K2]
+        # exchange 4: to natural blocks of the interleaved result, out[(K2 C + K1) b + s]; destination d owns K2 in [d R/W, (d+1) R/W)
+        send = self._perm(rows, (b, ncl, R), (2, 1, 0))                                     # [K2][K1 local][s] — dst-major since K2 = d R/W + K2 local
+        recv = exchange_all_to_all(send.view(W, -1, 4))                                    # [src p][K2 local][K1 local][s]
+        return self._perm(recv.view(-1, 4), (W, nrl, ncl * b), (1, 0, 2))                   # [K2 local][p][K1 local][s] = natural order
 
 
 def sharded_stop_len(n_local: int, arity: int) -> int:
@@ -594,7 +620,7 @@ class DistProver:
                 allv = all_gather_rows(top)
                 lay.top = p.merkle_build(params, lay.arity, l, allv, allv.shape[0], 0, nlev - 1, 1)
                 rt, _ = p.merkle_last_level(lay.top)
-                roots.append(rt[0].cpu().numpy().view(np.uint64))
+                roots.append(rt[:1])
             else:
                 n = lay.n
                 if lay.hashed:
@@ -609,8 +635,8 @@ class DistProver:
                     lay.tree = p.merkle_build_pairs(params, lay.arity, l, lay.f, s_l, n)
                 lay.top, lay.nlev_local, lay.local_lens = None, 0, []
                 rt, _ = p.merkle_last_level(lay.tree)
-                roots.append(rt[0].cpu().numpy().view(np.uint64))
-        self.roots = np.stack(roots)
+                roots.append(rt[:1])
+        self.roots = torch.cat(roots, dim=0).cpu().numpy().view(np.uint64)           # ONE download for the L + 1 roots
         if os.environ.get("STARK_DIST_CHECK"):        # diagnostic: every rank must hold the same roots
             mine = torch.from_numpy(self.roots.view(np.int64).copy())
             allr = all_gather_rows(mine.view(1, -1)).view(W, -1)

@@ -46,6 +46,20 @@ class CpuStandIn:
                 a[r, c, :] = self.o.mul(a[r, c, :], cur, self.field); cur = self.o.mul(cur, step, self.field)
         self.ntt_columns(slab, log_rows, ncols, col0, log_n, False)
 
+    def ntt_rows_coset(self, src, out, nrows, log_cols, row0, log_n, shift4):
+        # the definition: dst[i][m] = w_n^(k1 m) * NTT_C(src[i][k'] * shift^(k' R + k1))[m], k1 = row0 + i, R = 2^(log_n - log_cols)
+        o, f = self.o, self.field
+        a = self._np(src).reshape(nrows, 1 << log_cols, 4); d = self._np(out).reshape(nrows, 1 << log_cols, 4)
+        R = 1 << (log_n - log_cols); w = o.root_of_unity(log_n, f); step = o.pow(shift4, R, f)
+        for i in range(nrows):
+            k1 = row0 + i; cur = o.pow(shift4, k1, f); x = np.zeros_like(a[i])
+            for kp in range(1 << log_cols):
+                x[kp] = o.mul(a[i, kp], cur, f); cur = o.mul(cur, step, f)
+            y = o.ntt(f, x)
+            wk = o.pow(w, k1, f); tw = o.from_u64(1, f)
+            for m in range(1 << log_cols):
+                d[i, m] = o.mul(y[m], tw, f); tw = o.mul(tw, wk, f)
+
     def interleave(self, dst, src, stride, offset):
         dst.view(-1, stride, 4)[:, offset, :] = src
 
@@ -200,9 +214,11 @@ def _lde_worker(rank, world, port, log_n, log_rows, q):
         nl = n // world
         ev = o.synth_column(77, 0, 0, n)
         lde = sd.ShardedLde(prov, log_n, lb, 5, log_rows)
+        sd.STATS["all_to_all"] = 0
         out = lde(prov._t(ev[rank * nl:(rank + 1) * nl])).numpy().view(np.uint64)
         want = o.lde(0, ev, lb, o.from_u64(5))
         ok_lde = bool((out == want[rank * nl * 4:(rank + 1) * nl * 4]).all())
+        ok_lde = ok_lde and sd.STATS["all_to_all"] == lde.n_all_to_all == 4      # counted exchanges per column (at most 6)
         # the chained bench step: LDE of four columns -> merge -> sharded commit; roots must equal the oracle's for the whole trace
         cols = [o.synth_column(78, c, 0, n) for c in range(4)]
         z = o.from_u64(0xC0FFEE); coset = o.from_u64(5); sched = [8, 4]
