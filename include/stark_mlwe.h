@@ -64,6 +64,11 @@ int32_t stark_version(void);
  * context is one device; the communicator that spans the GPUs is stark_comm_* below.) */
 #define STARK_STREAM_PRIVATE ((void*)(intptr_t)-1)
 int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out);
+/* Lifetime: every handle made from a context (stark_tree_t, stark_fri_state_t, stark_fri_plan_t, stark_transcript_t, a stark_params_t returned
+ * to the caller) keeps the context alive.  stark_ctx_destroy with such handles outstanding synchronises, marks the context and returns
+ * STARK_OK; the handles stay fully usable and the last one freed releases the context's resources.  Device pointers obtained FROM a handle
+ * (stark_merkle_level_dev, layers of a FRI state) are valid for work ordered on the context's stream until the handle is freed: freeing
+ * returns the block to the context's pool without a device synchronisation, so a caller that read it on ANOTHER stream synchronises first. */
 int32_t stark_ctx_destroy(stark_ctx_t* ctx);
 int32_t stark_ctx_sync(stark_ctx_t* ctx);
 /* The library keeps released temporaries / layers / tree levels in a per-context cache (no hipMalloc /

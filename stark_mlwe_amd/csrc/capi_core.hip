@@ -250,9 +250,9 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     (void)hipFuncSetAttribute((const void*)k_hash_ds2<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     *out = c; return STARK_OK;
 }
-int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
-    if (!ctx) return STARK_ERR_INVALID_ARG;
-    STARK_TRY(ctx_enter(ctx));
+}  // extern "C"
+// everything the context owns; runs when the context has been destroyed AND its last handle is gone
+static void ctx_teardown(stark_ctx* ctx) {
     (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
     stark::comm_destroy(ctx);
     stark::ntt_plans_free(ctx);
@@ -263,14 +263,28 @@ int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& o : ctx->omega_tabs) { (void)hipFree(o.lo); (void)hipFree(o.hi); }
     for (auto& kv : ctx->pool_free) for (void* q : kv.second) (void)hipFree(q);
-    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);                 // handles the caller never freed
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);                 // stark_alloc blocks the caller never freed (handles are gone by now)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0); if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx; return STARK_OK;
+    delete ctx;
+}
+namespace stark {
+void ctx_ref(stark_ctx* c) { ++c->live_handles; }
+void ctx_unref(stark_ctx* c) { if (--c->live_handles == 0 && c->destroy_pending) ctx_teardown(c); }
+}
+extern "C" {
+// With handles still alive (trees, FRI states, plans, transcripts, parameter sets made for the caller) the context is only MARKED here: it stops
+// accepting new work through stark_ctx_* but stays valid for those handles, and the last of them to be freed tears it down.
+int32_t stark_ctx_destroy(stark_ctx_t* ctx) {
+    if (!ctx) return STARK_ERR_INVALID_ARG;
+    if (ctx->destroy_pending) return STARK_ERR_INVALID_ARG;                  // destroyed twice
+    STARK_TRY(ctx_enter(ctx));
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->live_handles > 0) { ctx->destroy_pending = true; return STARK_OK; }
+    ctx_teardown(ctx); return STARK_OK;
 }
 int32_t stark_ctx_sync(stark_ctx_t* ctx) { if (!ctx) return STARK_ERR_INVALID_ARG; STARK_TRY(ctx_enter(ctx)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return STARK_OK; }
 int32_t stark_ctx_trim(stark_ctx_t* ctx) {
@@ -351,18 +365,18 @@ int32_t stark_poseidon_params_upload(stark_ctx_t* ctx, int32_t t, int32_t rf, in
     for (size_t i = 0; i < c.mds.size(); ++i) c.mds[i] = load_fr(mds + 4 * i);
     for (size_t i = 0; i < c.rc_full.size(); ++i) c.rc_full[i] = load_fr(rc_full + 4 * i);
     for (size_t i = 0; i < c.rc_partial.size(); ++i) c.rc_partial[i] = load_fr(rc_partial + 4 * i);
-    return params_from_consts(ctx, c, out);
+    { int32_t rc = params_from_consts(ctx, c, out); if (rc == STARK_OK) (*out)->ref_.bind(ctx); return rc; }   // a set handed to the caller keeps the context alive
 }
 int32_t stark_poseidon_params_for_width(stark_ctx_t* ctx, int32_t t, stark_params_t** out) {
     if (!ctx || !out) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
     if (host::rp_for_width(t) < 0) return ctx->fail(STARK_ERR_UNSUPPORTED, "unsupported Poseidon width t; supported t in {9,17,33,65,129}");   // poseidon/src/lib.rs:127
-    return params_from_consts(ctx, host::consts_for_width(t), out);
+    { int32_t rc = params_from_consts(ctx, host::consts_for_width(t), out); if (rc == STARK_OK) (*out)->ref_.bind(ctx); return rc; }   // a set handed to the caller keeps the context alive
 }
 int32_t stark_poseidon_params_t17_seed(stark_ctx_t* ctx, const uint8_t* seed, size_t n, stark_params_t** out) {
     if (!ctx || !out || (!seed && n)) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
-    return params_from_consts(ctx, host::derive_consts(std::string((const char*)seed, n), 17, 8, 64), out);
+    { int32_t rc = params_from_consts(ctx, host::derive_consts(std::string((const char*)seed, n), 17, 8, 64), out); if (rc == STARK_OK) (*out)->ref_.bind(ctx); return rc; }   // a set handed to the caller keeps the context alive
 }
 int32_t stark_poseidon_params_export(stark_params_t* p, int32_t* t, int32_t* rf, int32_t* rp, uint64_t* mds, uint64_t* rc_full, uint64_t* rc_partial) {
     if (!p) return STARK_ERR_INVALID_ARG;
@@ -530,7 +544,7 @@ int32_t merkle_build_on(stark_ctx* ctx, hipStream_t st, stark_params* p, size_t 
     if (n == 0) return ctx->fail(STARK_ERR_INVALID_ARG, "no leaves");                                                 // merkle/src/lib.rs:148
     if (host::width_for_arity(arity) != p->dev.t) return ctx->fail(STARK_ERR_INVALID_ARG, "arity incompatible with Poseidon width");   // :155-161
     if (arity == 1 && n > 1) return ctx->fail(STARK_ERR_UNSUPPORTED, "arity 1 with more than one leaf never terminates in the reference");
-    stark_tree* T = new stark_tree(); T->ctx = ctx; T->p = p; T->arity = arity; T->label = label;
+    stark_tree* T = new stark_tree(); T->ref_.bind(ctx); T->ctx = ctx; T->p = p; T->arity = arity; T->label = label;
     auto bail = [&](int32_t rc) { delete T; return rc; };
     fr_t* l0 = nullptr;
     if (adopt && !pairs) l0 = const_cast<fr_t*>(leaves);

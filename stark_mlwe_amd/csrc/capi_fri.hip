@@ -11,6 +11,7 @@
 using namespace stark;
 
 struct stark_fri_state {
+    CtxRef ref_;
     stark_ctx* ctx = nullptr;
     std::vector<size_t> schedule;
     std::vector<fr_t*> f; std::vector<size_t> n;           // L+1 layers (device, pooled)
@@ -89,7 +90,7 @@ static int32_t state_roots(stark_fri_state* S) {
 static int32_t fri_build_impl(stark_ctx* ctx, const fr_t* f0_dev, size_t n0, const size_t* schedule, size_t L, uint64_t seed_z, stark_fri_state** out) {
     if (!n0) return ctx->fail(STARK_ERR_INVALID_ARG, "empty layer");
     { size_t n = n0; for (size_t l = 0; l < L; ++l) { if (schedule[l] < 2 || n % schedule[l]) return ctx->fail(STARK_ERR_INVALID_ARG, "schedule not dividing domain size"); n /= schedule[l]; } }   // fri.rs:150
-    stark_fri_state* S = new stark_fri_state(); S->ctx = ctx; S->schedule.assign(schedule, schedule + L);
+    stark_fri_state* S = new stark_fri_state(); S->ref_.bind(ctx); S->ctx = ctx; S->schedule.assign(schedule, schedule + L);
     auto bail = [&](int32_t rc) { delete S; return rc; };
     // Everything that may upload constants (and synchronise doing so) happens BEFORE any stream is forked: transcript
     // parameters, the leaf template, the Merkle parameters of every layer, the challenges.  After the first call these are all cached.
@@ -313,7 +314,7 @@ static int32_t prove_queries_encode(stark_ctx* ctx, stark_fri_state* S, size_t n
 }
 
 // Query plan of a commit phase whose layers live elsewhere (sharded over ranks): see fri_plan.hpp.
-struct stark_fri_plan { stark_ctx* ctx = nullptr; FriPlan plan; };
+struct stark_fri_plan { CtxRef ref_; stark_ctx* ctx = nullptr; FriPlan plan; };
 
 static int32_t prove_impl(stark_ctx* ctx, const fr_t* a, const fr_t* s, const fr_t* e, const fr_t* t, const fr_t* f0_in, size_t n0,
                           const size_t* schedule, size_t L, size_t r, uint64_t seed_z, stark_proof** out) {
@@ -528,7 +529,7 @@ int32_t stark_fri_plan_create(stark_ctx_t* ctx, const uint64_t* roots, size_t n0
     if (!ctx || !roots || !out || (!schedule && L)) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));
     std::vector<fr_t> rt(L + 1); for (size_t l = 0; l <= L; ++l) rt[l] = load_fr(roots + 4 * l);
-    stark_fri_plan* P = new stark_fri_plan(); P->ctx = ctx; P->plan.r = r;
+    stark_fri_plan* P = new stark_fri_plan(); P->ref_.bind(ctx); P->ctx = ctx; P->plan.r = r;
     std::string err; if (!P->plan.shape.make(n0, schedule, L, rt.data(), err)) { delete P; return ctx->fail(STARK_ERR_INVALID_ARG, err); }
     DeviceHasher H(ctx); int32_t rc = fri_plan_make(P->plan, H);
     if (rc) { delete P; return rc == -1 ? ctx->fail(STARK_ERR_INVALID_ARG, "query plan") : rc; }

@@ -18,7 +18,20 @@ struct NttPlan;
 
 }  // namespace stark
 
+// Handles (trees, FRI states, plans, transcripts, caller-made parameter sets) keep their context alive: stark_ctx_destroy with live handles
+// only marks the context; the LAST handle freed tears it down.  `CtxRef` is the FIRST member of every handle type, so it is destroyed last — after
+// the handle's own destructor has returned its blocks to the context's pool.  (A Rust host drops its thread-local context at thread exit while
+// Tree / ProverState values owned by the caller may outlive it — ADVICE r2.)
+namespace stark { void ctx_ref(stark_ctx* c); void ctx_unref(stark_ctx* c); }
+struct CtxRef {
+    stark_ctx* c = nullptr;
+    CtxRef() = default; CtxRef(const CtxRef&) = delete; CtxRef& operator=(const CtxRef&) = delete;
+    void bind(stark_ctx* x) { if (x) stark::ctx_ref(x); if (c) stark::ctx_unref(c); c = x; }
+    ~CtxRef() { if (c) stark::ctx_unref(c); }
+};
+
 struct stark_params {
+    CtxRef ref_;                         // bound only for parameter sets handed to the caller (the context's own cached sets do not pin it)
     stark_ctx* ctx = nullptr;
     stark::host::PoseidonConsts ref;     // reference-form constants (as uploaded / derived)
     stark::host::KernelConsts kc;        // kernel-form constants
@@ -35,6 +48,7 @@ struct stark_ctx {
     bool own_stream = false;
     hipStream_t side_stream = nullptr;               // lazily created: small independent jobs that run underneath a big one (fri_build)
     std::string err;
+    int live_handles = 0; bool destroy_pending = false;   // see CtxRef
     hipEvent_t ev0 = nullptr, ev1 = nullptr;         // stark_timer_start / stop
     hipEvent_t ev_fork = nullptr;                    // orders the side stream after the main one
     // lazily created constants
@@ -76,6 +90,7 @@ int32_t ctx_alloc(stark_ctx* ctx, size_t bytes, void** out);   // pooled device 
 void ctx_release(stark_ctx* ctx, void* p);
 }
 struct stark_tree {
+    CtxRef ref_;
     stark_ctx* ctx = nullptr; stark_params* p = nullptr;
     size_t arity = 0; uint64_t label = 0;
     std::vector<stark::fr_t*> levels; std::vector<size_t> lens; std::vector<char> owned;

@@ -287,6 +287,7 @@ static int32_t prove_mf_impl(stark_ctx* ctx, const fr_t* witness, size_t k, uint
         std::swap(cur_tree.t, next_tree.t); cur_root = next_root; layer = nx; len = half;
     }
     std::vector<fr_t> fin; STARK_TRY(read_elems(ctx, layer, {0}, fin));
+    T.absorb_str("SUMCHECK/MF/FINAL/EVAL"); T.absorb_field(fin[0]);          // finalize_eval (:732-738): bound, nothing is drawn after it (queued, never launched)
     stark_proof* P = new stark_proof(); BinW W(P->bytes);
     W.fb(initial_root); W.u64(rounds.size());
     for (auto& R : rounds) { W.fb(R.c0); W.fb(R.c1); W.fb(R.next_root); W.idxs(R.cur_indices); W.fvec(R.cur_values); W.mproof(R.cur_proof); W.idxs(R.next_indices); W.fvec(R.next_values); W.mproof(R.next_proof); }
@@ -366,7 +367,7 @@ static int32_t verify_mf_impl(stark_ctx* ctx, uint64_t tree_label, const uint8_t
 }  // namespace
 
 // ---- the streaming transcript as an object of the ABI (transcript/src/lib.rs:48-117) ------------------------------------------
-struct stark_transcript { DevTranscript T; explicit stark_transcript(stark_ctx* c) : T(c) {} };
+struct stark_transcript { CtxRef ref_; DevTranscript T; explicit stark_transcript(stark_ctx* c) : T(c) { ref_.bind(c); } };
 
 extern "C" {
 

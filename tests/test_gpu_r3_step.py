@@ -134,3 +134,29 @@ def test_reference_bench_presets_match_oracle_golden(gpu_ctx, label, sched, k):
     assert len(proof) == gold["proof_len"] and est == gold["size_estimate"]
     assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
     assert gpu_ctx.deep_fri_verify(DeepFriParams(sched, 32, gold["seed_z"]), proof)
+
+
+def test_handles_outlive_their_context(oracle):
+    """a tree / FRI state / transcript freed AFTER stark_ctx_destroy used to touch a freed context (use-after-free in the pool).
+    Handles now keep the context alive: destroy with handles outstanding only marks it, the handles stay usable, the last free tears it down."""
+    import numpy as np
+    from stark_mlwe_amd.api import Context, _ptr
+    ctx = Context(0)
+    lib = ctx.lib
+    leaves = oracle.synth_column(9, 1, 0, 512)
+    want = oracle.merkle_build(16, 7, leaves)
+    p = C.c_void_p(); ctx._chk(lib.stark_poseidon_params_for_width(ctx.h, 17, C.byref(p)))
+    t = C.c_void_p(); ctx._chk(lib.stark_merkle_build(ctx.h, p, 16, 7, _ptr(leaves), 512, 0, None, C.byref(t)))
+    f0 = oracle.synth_column(10, 2, 0, 1 << 10); sch = np.ascontiguousarray([16, 8], dtype=np.uint64)
+    st = C.c_void_p(); ctx._chk(lib.stark_fri_build(ctx.h, _ptr(f0), 1 << 10, _ptr(sch), 2, 0xDEEFBAAD, C.byref(st)))
+    h = ctx.h; ctx.h = None                                  # the Python wrapper must not destroy it a second time
+    assert lib.stark_ctx_destroy(h) == 0                     # three handles outstanding: marked, not torn down
+    assert lib.stark_ctx_destroy(h) == -1                    # a second destroy is an error, not a double free
+    root = np.zeros(4, np.uint64); assert lib.stark_merkle_root(t, _ptr(root)) == 0
+    assert (root == want.root()).all()
+    r0 = np.zeros(4, np.uint64); assert lib.stark_fri_layer_root(st, 0, _ptr(r0)) == 0
+    ref = oracle.deep_fri_prove(None, None, None, None, 1 << 10, [16, 8], 1, 0xDEEFBAAD, f0=f0)
+    assert (r0 == ref.root(0)).all(); ref.free(); want.free()
+    assert lib.stark_fri_state_free(st) == 0
+    assert lib.stark_merkle_free(t) == 0
+    assert lib.stark_poseidon_params_free(p) == 0            # the last handle: the context is released here
