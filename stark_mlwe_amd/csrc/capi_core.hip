@@ -9,6 +9,7 @@
 #include "poseidon_dev.hpp"
 #include "poseidon_pair.hpp"
 #include "poseidon_coop.hpp"
+#include "poseidon_chain.hpp"
 #include "fri_dev.hpp"
 
 using namespace stark;
@@ -83,7 +84,7 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     size_t o_rcf = put(k.rc_full), o_rcp = put(k.rc_partial), o_lu = put(k.lu), o_pre = put(k.lu_pre), o_row0 = put(k.row0), o_sp = put(k.sparse), o_mds = put(k.mds), o_mpre = put(k.mds_pre), o_gam = put(k.gamma);
     // radix-2^29 multiplier tables (fr29.hpp), appended to the same device blob as raw words
     const size_t o_29 = blob.size();
-    { std::vector<uint32_t> w29; for (auto* v : {&k.lu29, &k.lu_pre29, &k.row0_29, &k.sparse29, &k.gamma29, &k.mds29, &k.mds_pre29}) w29.insert(w29.end(), v->begin(), v->end());
+    { std::vector<uint32_t> w29; for (auto* v : {&k.lu29, &k.lu_pre29, &k.row0_29, &k.sparse29, &k.gamma29, &k.mds29, &k.mds_pre29, &k.chain_a, &k.chain_g, &k.chain_w}) w29.insert(w29.end(), v->begin(), v->end());
       while (w29.size() % 8) w29.push_back(0);
       blob.resize(o_29 + w29.size() / 8); memcpy((void*)(blob.data() + o_29), w29.data(), w29.size() * 4); }
     // int8 MFMA fragments of the dense matrices (t = 17), raw bytes in the same blob
@@ -98,7 +99,9 @@ static int32_t params_finish(stark_ctx* ctx, stark_params* P) {
     { const uint32_t* b29 = reinterpret_cast<const uint32_t*>(P->blob + o_29);
       P->dev.lu29 = b29; P->dev.lu_pre29 = b29 + k.lu29.size(); P->dev.row0_29 = P->dev.lu_pre29 + k.lu_pre29.size();
       P->dev.sparse29 = P->dev.row0_29 + k.row0_29.size(); P->dev.gamma29 = P->dev.sparse29 + k.sparse29.size();
-      P->dev.mds29 = P->dev.gamma29 + k.gamma29.size(); P->dev.mds_pre29 = P->dev.mds29 + k.mds29.size(); }
+      P->dev.mds29 = P->dev.gamma29 + k.gamma29.size(); P->dev.mds_pre29 = P->dev.mds29 + k.mds29.size();
+      const uint32_t* ch = P->dev.mds_pre29 + k.mds_pre29.size();
+      P->dev.chain_a = k.chain_a.empty() ? nullptr : ch; P->dev.chain_g = k.chain_a.empty() ? nullptr : ch + k.chain_a.size(); P->dev.chain_w = k.chain_a.empty() ? nullptr : ch + k.chain_a.size() + k.chain_g.size(); }
     P->dev.mds_frag = k.mds_frag.empty() ? nullptr : (const void*)(P->blob + o_frag); P->dev.mds_pre_frag = k.mds_frag.empty() ? nullptr : (const void*)(P->blob + o_frag + frag_elems);
     return STARK_OK;
 }
@@ -143,12 +146,19 @@ static int32_t tr_frame(stark_ctx* ctx, const char* label, const char* tag, cons
     }
     *dev = it->second; *np = ctx->tr_frame_dims[key].first; *ns = ctx->tr_frame_dims[key].second; return STARK_OK;
 }
+static int32_t launch_column_sponges(stark_ctx* ctx, stark_params* tp, const TrMultiJob& J, unsigned nblocks, fr_t* out_dev);
 int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, size_t k, size_t n, fr_t* out_dev) {
     hipStream_t st = ctx->stream;
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
     fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tag, "out", &frame, &np, &ns));
     if (n == 0) return STARK_OK;
     TrJob J; J.prefix = frame; J.np = np; J.suffix = frame + np; J.ns = ns; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.k = k; J.n = n;
+    if (!ctx->opt_poseidon_lane_only && !ctx->opt_sponge_one_wave && tp->dev.chain_a && n <= 1024 && k >= 128) {
+        // a few LONG sponges (a column digest of a sharded prove, a long Fiat-Shamir input): three waves per chain (poseidon_chain.hpp)
+        TrMultiJob M; M.cap = J.cap; M.batch = nullptr; M.stride = k;
+        for (int c = 0; c < 4; ++c) { M.prefix[c] = frame; M.np[c] = np; M.suffix[c] = frame + np; M.ns[c] = ns; M.fields[c] = fields_dev; M.k[c] = k; }
+        return launch_column_sponges(ctx, tp, M, (unsigned)n, out_dev);
+    }
     if (!ctx->opt_poseidon_lane_only && n <= 4096) {
         // few (or one, possibly very long) sponges: one wave per sponge, latency-oriented (poseidon_coop.hpp)
         hipLaunchKernelGGL(k_tr_hash_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(17), st, tp->dev, J, fields_dev, out_dev);
@@ -160,28 +170,37 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     STARK_HIP(ctx, hipGetLastError());
     return STARK_OK;
 }
+// Long serial sponges: three waves per chain (poseidon_chain.hpp) unless the option "sponge_one_wave" asks for the round-2 one-wave form.
+static int32_t launch_column_sponges(stark_ctx* ctx, stark_params* tp, const TrMultiJob& J, unsigned nblocks, fr_t* out_dev) {
+    if (tp->dev.chain_a && !ctx->opt_sponge_one_wave) {
+        const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i];
+        hipLaunchKernelGGL(k_tr_hash_chain, dim3(nblocks), dim3(192), chain_lds_bytes(), ctx->stream, tp->dev, J, RK, out_dev);
+    } else {
+        hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(nblocks), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out_dev);
+    }
+    STARK_HIP(ctx, hipGetLastError());
+    return STARK_OK;
+}
 // The four column sponges of DeepAliRealBuilder::build_f0 (fri.rs:551-554) as one launch of four blocks.
 int32_t tr_hash_columns4_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const cols[4], size_t n0, fr_t* out4_dev) {
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
-    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.batch = nullptr;
+    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.batch = nullptr; J.stride = 0;
     for (int c = 0; c < 4; ++c) {
         fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tags[c], "out", &frame, &np, &ns));
         J.prefix[c] = frame; J.np[c] = np; J.suffix[c] = frame + np; J.ns[c] = ns; J.fields[c] = cols[c]; J.k[c] = n0;
     }
-    hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(4), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out4_dev);
-    STARK_HIP(ctx, hipGetLastError());
+    STARK_TRY(launch_column_sponges(ctx, tp, J, 4, out4_dev));
     return STARK_OK;
 }
 // The same for B independent traces: 4 * B chains, one block each, in one launch.  ptrs_dev[4 * p + c] = column c of trace p (device array of device pointers).
 int32_t tr_hash_columns_batch_dev(stark_ctx* ctx, const char* const tags[4], const fr_t* const* ptrs_dev, size_t batch, size_t n0, fr_t* out_dev) {
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
-    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.batch = ptrs_dev;
+    TrMultiJob J; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.batch = ptrs_dev; J.stride = 0;
     for (int c = 0; c < 4; ++c) {
         fr_t* frame = nullptr; int np = 0, ns = 0; STARK_TRY(tr_frame(ctx, "FRI/FS", tags[c], "out", &frame, &np, &ns));
         J.prefix[c] = frame; J.np[c] = np; J.suffix[c] = frame + np; J.ns[c] = ns; J.fields[c] = nullptr; J.k[c] = n0;
     }
-    hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3((unsigned)(4 * batch)), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out_dev);
-    STARK_HIP(ctx, hipGetLastError());
+    STARK_TRY(launch_column_sponges(ctx, tp, J, (unsigned)(4 * batch), out_dev));
     return STARK_OK;
 }
 int32_t tr_hash_host1(stark_ctx* ctx, const char* tag, const std::vector<fr_t>& fields, fr_t* out) {
@@ -305,6 +324,7 @@ int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value) {
     else if (k == "ntt_log_tile") { if (value != -1 && (value < 8 || value > 12)) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_log_tile: 8..12, or -1 for the default"); ctx->opt_ntt_log_tile_forced = value != -1; ctx->opt_ntt_log_tile = value == -1 ? 11 : (int)value; }
     else if (k == "ntt_min_waves") { if (value != 2 && value != 4) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_min_waves: 2 or 4"); ctx->opt_ntt_min_waves = (int)value; }
     else if (k == "poseidon_lane_only") ctx->opt_poseidon_lane_only = value != 0;
+    else if (k == "sponge_one_wave") ctx->opt_sponge_one_wave = value != 0;
     else return ctx->fail(STARK_ERR_INVALID_ARG, "unknown option '" + k + "' (ntt_direct_max_log, ntt_log_tile, ntt_min_waves, poseidon_lane_only)");
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     stark::ntt_plans_free(ctx);                  // plans (and their direct tables) are rebuilt lazily under the new options

@@ -204,6 +204,14 @@ struct KernelConsts {
     std::vector<uint32_t> mds29, mds_pre29;   // dense forms for the one-wave kernel (every entry meets an S-box output: all scaled)
     // t = 17 only: the dense matrices as int8 MFMA operand fragments (signed radix-256 digits, Toeplitz windows), see mfma_frags
     std::vector<int8_t> mds_frag, mds_pre_frag;
+    // t = 17 only: the partial rounds UNROLLED over all rp rounds for the three-wave latency kernel (poseidon_chain.hpp):
+    //     X_{q+1} = c_{q+1} + sum_j u_{q,j} s_j^(0) + a_q y_q + sum_{p<q} Gamma_{q,p} y_p,   y_q = X_q^5,   Gamma_{q,p} = sum_j u_{q,j} w_{p,j}
+    // Every entry multiplies a y that reaches it through THREE Montgomery steps by 2^261 on operands carrying 2^256, so it is stored as
+    // nine 29-bit limbs of c * 2^25 * 2^256 mod r (= c * (2^261)^5 / (2^256)^4): the product lands back in the 2^256 domain.
+    //   chain_a [rp][64]      lane 16 + c: limb c of a_q; lane 32 + c: limb c of Gamma_{q+1,q} (0 for the last round); other lanes 0
+    //   chain_g [rp][9][64]   limb i of Gamma_{q,p} for lane q >= p + 2, else 0   (p = first index)
+    //   chain_w [rp][t-1][9]  w_{p,j}
+    std::vector<uint32_t> chain_a, chain_g, chain_w;
     bool ok = false;
 };
 // scaled(i) == true: the entry multiplies an S-box output, which fr_pow5_r29 delivers as x^5 / 2^20 (fr29.hpp)
@@ -308,6 +316,26 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     k.sparse29 = to_radix29(k.sparse, a_and_w); k.gamma29 = to_radix29(k.gamma, all);
     k.mds29 = to_radix29(k.mds, all); k.mds_pre29 = to_radix29(k.mds_pre, all);
     if (t == 17) { k.mds_frag = mfma_frags(k.mds, t); k.mds_pre_frag = mfma_frags(k.mds_pre, t); }      // the wave-pair kernels' full rounds (poseidon_pair.hpp)
+    if (t == 17 && c.rp == 64) {                                                                         // the three-wave latency kernel (poseidon_chain.hpp)
+        const int rp = c.rp, w = 2 * t - 1;
+        const fr_t scale = fr_from_u64<PF>(1ull << 25);
+        auto limbs = [&](const fr_t& v, uint32_t* out) { const fr29_t u = fr29_unpack(h_mul(v, scale)); for (int i = 0; i < 9; ++i) out[i] = u.l[i]; };
+        k.chain_a.assign((size_t)rp * 64, 0u); k.chain_g.assign((size_t)rp * 9 * 64, 0u); k.chain_w.assign((size_t)rp * (t - 1) * 9, 0u);
+        for (int q = 0; q < rp; ++q) {
+            uint32_t l[9]; limbs(k.sparse[(size_t)q * w], l);
+            for (int i = 0; i < 9; ++i) k.chain_a[(size_t)q * 64 + 16 + i] = l[i];
+            for (int j = 1; j < t; ++j) limbs(k.sparse[(size_t)q * w + t - 1 + j], &k.chain_w[((size_t)q * (t - 1) + (j - 1)) * 9]);
+        }
+        for (int q = 1; q < rp; ++q)
+            for (int p2 = 0; p2 < q; ++p2) {
+                const fr_t* uq = &k.sparse[(size_t)q * w]; const fr_t* wp = &k.sparse[(size_t)p2 * w];
+                fr_t acc = h_zero();
+                for (int j = 1; j < t; ++j) acc = h_add(acc, h_mul(uq[j], wp[t - 1 + j]));
+                uint32_t l[9]; limbs(acc, l);
+                if (q == p2 + 1) { for (int i = 0; i < 9; ++i) k.chain_a[(size_t)p2 * 64 + 32 + i] = l[i]; }             // Gamma_{p+1,p}: wave A's third row in round p
+                else for (int i = 0; i < 9; ++i) k.chain_g[((size_t)p2 * 9 + i) * 64 + q] = l[i];                          // q >= p + 2: wave B, lane q
+            }
+    }
     k.ok = true;
     return k;
 }

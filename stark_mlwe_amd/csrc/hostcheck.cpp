@@ -13,6 +13,7 @@
 #include "fri_plan.hpp"
 #include "fri_verify.hpp"
 #include "mfma_digits.hpp"
+#include "poseidon_chain.hpp"
 
 using namespace stark;
 
@@ -25,6 +26,8 @@ static void bind(HcParams* P) {
     P->dev.t = P->kc.t; P->dev.rf = P->kc.rf; P->dev.rp = P->kc.rp; P->dev.rc_full = P->kc.rc_full.data(); P->dev.rc_partial = P->kc.rc_partial.data();
     P->dev.lu = P->kc.lu.data(); P->dev.lu_pre = P->kc.lu_pre.data(); P->dev.row0 = P->kc.row0.data(); P->dev.sparse = P->kc.sparse.data(); P->dev.mds = P->kc.mds.data(); P->dev.mds_pre = P->kc.mds_pre.data(); P->dev.gamma = P->kc.gamma.data();
     P->dev.lu29 = P->kc.lu29.data(); P->dev.lu_pre29 = P->kc.lu_pre29.data(); P->dev.row0_29 = P->kc.row0_29.data(); P->dev.sparse29 = P->kc.sparse29.data(); P->dev.gamma29 = P->kc.gamma29.data(); P->dev.mds29 = P->kc.mds29.data(); P->dev.mds_pre29 = P->kc.mds_pre29.data();
+    P->dev.mds_frag = nullptr; P->dev.mds_pre_frag = nullptr;
+    P->dev.chain_a = P->kc.chain_a.empty() ? nullptr : P->kc.chain_a.data(); P->dev.chain_g = P->kc.chain_g.empty() ? nullptr : P->kc.chain_g.data(); P->dev.chain_w = P->kc.chain_w.empty() ? nullptr : P->kc.chain_w.data();
 }
 
 extern "C" {
@@ -179,6 +182,21 @@ int hc_full_round_linear(void* h, int which, int pre, uint64_t* states, size_t n
 int hc_permute_kernel_form(void* h, uint64_t* states, size_t n) {
     HcParams* P = (HcParams*)h; int t = P->dev.t; std::vector<fr_t> st(t);
     for (size_t i = 0; i < n; ++i) { for (int j = 0; j < t; ++j) st[j] = ld4(states + 4 * (i * t + j)); ArrayState s{st.data()}; permute_core(s, P->dev, false); for (int j = 0; j < t; ++j) st4(states + 4 * (i * t + j), st[j]); }
+    return 0;
+}
+// the permutation with its partial rounds UNROLLED over all rp rounds from the chain tables (poseidon_chain.hpp chain_partial_model: the algebra and
+// table scaling of the three-wave latency kernel); full rounds dense.  t = 17 only.
+int hc_permute_chain_model(void* h, uint64_t* states, size_t n) {
+    HcParams* P = (HcParams*)h; const int t = P->ref.t, half = P->ref.rf / 2; if (!P->dev.chain_a) return -1;
+    std::vector<fr_t> st(t), o(t);
+    auto dense = [&](const std::vector<fr_t>& M) { for (int i = 0; i < t; ++i) { fr_t acc = host::h_zero(); for (int j = 0; j < t; ++j) acc = host::h_add(acc, host::h_mul(M[(size_t)i * t + j], st[j])); o[i] = acc; } st = o; };
+    for (size_t i = 0; i < n; ++i) {
+        for (int j = 0; j < t; ++j) st[j] = ld4(states + 4 * (i * t + j));
+        for (int r = 0; r < half; ++r) { for (int j = 0; j < t; ++j) st[j] = fr_pow5<PallasFr>(host::h_add(st[j], P->ref.rc_full[(size_t)r * t + j])); dense(r == half - 1 ? P->kc.mds_pre : P->kc.mds); }
+        chain_partial_model(st.data(), P->dev);
+        for (int r = half; r < P->ref.rf; ++r) { for (int j = 0; j < t; ++j) st[j] = fr_pow5<PallasFr>(host::h_add(st[j], P->ref.rc_full[(size_t)r * t + j])); dense(P->kc.mds); }
+        for (int j = 0; j < t; ++j) st4(states + 4 * (i * t + j), st[j]);
+    }
     return 0;
 }
 // reference-form (dense) permutation on the host, from the same constants

@@ -1,0 +1,315 @@
+// stark_mlwe_amd/csrc/poseidon_chain.hpp — the serial sponge as THREE cooperating waves (gfx950): the latency form of round 3.
+//
+// The column sponges of DeepAliRealBuilder::build_f0 (crates/deep_ali/src/fri.rs:548-557 via tr_hash_fields_tagged, fri.rs:28-35) are
+// n0/16 DEPENDENT t = 17 permutations per column; they are 99.7 % of an end-to-end prove.  One wave per sponge (poseidon_coop.hpp) spends
+// 109 of its 143 us per permutation in the 64 partial rounds, three product latencies each, and on a lone wave a product is bound by the
+// number of instructions one lane executes (81 + 36 multiply-accumulates and their carries: 400 ns).
+//
+// Here the partial rounds are UNROLLED over all 64 rounds (host_util.hpp chain tables):
+//     X_{q+1} = [ c_{q+1} + sum_j u_{q,j} s_j^(0) ]  +  a_q y_q  +  Gamma_{q,q-1} y_{q-1}  +  sum_{p <= q-2} Gamma_{q,p} y_p ,   y_q = X_q^5
+//                 E_q (wave C)                          wave A        wave A (previous round)   H_q - E_q (wave B)
+// so that only X -> X^2 -> (a X) X^2 X^2 is on the dependent chain, and that chain runs in ROW FORM on wave A (poseidon_row, below): one
+// product spread over the 16 lanes of a DPP row, limb c on lane c — 9 + 9 + 5 multiply-accumulates per lane-parallel product instead of 117
+// on one lane: 250 ns per dependent product (tools/chain_row.hip, profiles/r03_chain_row_product.jsonl).  Four rows = four products per
+// slot sharing one broadcast operand: row 0 the chain (X^2, X^3, X^5), row 1 a_q X -> a_q y_q, row 2 Gamma_{q+1,q} X -> Gamma_{q+1,q} y_q.
+//   wave B  lane q keeps H_q: every round it adds Gamma_{q,p} y_p for all q >= p + 2 at once (one one-lane product, 64 lanes) and publishes
+//           H_{p+2}; it has a full round of slack.
+//   wave C  first E_q for all q (16-term dot products, four at a time, far ahead of the chain), then the lanes of the state,
+//           s_j = s_j^(0) + sum_p w_{p,j} y_p (four rounds per product slot), finished one product after the chain ends.
+// The waves talk through LDS mailboxes and monotonic counters (no barrier inside the 64 rounds); the eight full rounds stay on wave A as in
+// poseidon_coop.hpp.  The same field values as the reference's dense rounds: the host model below (chain_partial_model) is checked against
+// permute_dense in tests/test_hostcheck.py, the kernel against the oracle on the GPU.
+#pragma once
+#include "fr.hpp"
+#include "fr29.hpp"
+#include "poseidon_params.hpp"
+#if defined(__HIPCC__)
+#include "poseidon_coop.hpp"      // full rounds on one wave, nine-limb helpers, TrMultiJob
+#endif
+
+namespace stark {
+
+// ---- host + device: the unrolled partial rounds from the chain tables, with the one-lane product (the definition the kernel follows) ----
+// s: the state after the first rf/2 full rounds (what permute_core / coop_permute hold when their partial loop starts); on return the state
+// after the rp partial rounds.  Values are canonicalised between steps: this is the model of the algebra and of the tables' scaling, not of
+// the lazy limb bounds (those are asserted by tools/chain_row_check.py and by the kernel's GPU tests).
+FR_HD void chain_partial_model(fr_t* s, const PoseidonDev& P) {
+    const int t = P.t, rp = P.rp, w = 2 * t - 1;
+    auto mont = [](const uint32_t* c, const fr29_t& b) { fr29_t a; for (int i = 0; i < 9; ++i) a.l[i] = c[i]; return fr29_mul_mont<PF>(a, b); };
+    auto canon = [](const fr29_t& v) { return fr29_pack_reduce<PF>(v.l); };
+    fr_t H[64], F[16], prevG = fr_zero<PF>();
+    for (int q = 0; q < rp; ++q) {                                                                            // wave C: E_q
+        fr_t e = q + 1 < rp ? P.rc_partial[q + 1] : fr_zero<PF>();
+        for (int j = 1; j < t; ++j) e = fr_add<PF>(e, canon(mont(P.sparse29 + 9 * ((size_t)q * w + j), fr29_unpack(s[j]))));
+        H[q] = e;
+    }
+    for (int j = 0; j < t - 1; ++j) F[j] = s[j + 1];
+    fr_t X = fr_add<PF>(s[0], P.rc_partial[0]);
+    for (int q = 0; q < rp; ++q) {
+        const fr29_t xs = fr29_unpack(X);
+        const fr29_t x2 = fr29_mul_mont<PF>(xs, xs);                                                          // wave A, row 0
+        const fr29_t y = fr29_mul_mont<PF>(fr29_mul_mont<PF>(xs, x2), x2);                                    //   y' = X^5 R^5 / R'^4 ... (three steps by 2^261)
+        auto through = [&](const uint32_t* c) { return canon(fr29_mul_mont<PF>(fr29_mul_mont<PF>(mont(c, xs), x2), x2)); };   // rows 1, 2: (c X) X^2 X^2
+        uint32_t ca[9], cg[9];
+        for (int i = 0; i < 9; ++i) { ca[i] = P.chain_a[(size_t)q * 64 + 16 + i]; cg[i] = P.chain_a[(size_t)q * 64 + 32 + i]; }
+        const fr_t aterm = through(ca), gterm = through(cg);
+        for (int qq = q + 2; qq < rp; ++qq) {                                                                 // wave B
+            uint32_t c[9]; for (int i = 0; i < 9; ++i) c[i] = P.chain_g[((size_t)q * 9 + i) * 64 + qq];
+            H[qq] = fr_add<PF>(H[qq], canon(mont(c, y)));
+        }
+        for (int j = 0; j < t - 1; ++j) F[j] = fr_add<PF>(F[j], canon(mont(P.chain_w + ((size_t)q * (t - 1) + j) * 9, y)));   // wave C
+        X = fr_add<PF>(fr_add<PF>(H[q], aterm), prevG);
+        prevG = gterm;
+    }
+    s[0] = X;
+    for (int j = 0; j < t - 1; ++j) s[j + 1] = F[j];
+}
+
+// Host: the constants of the row-form Montgomery step (row::mul below) for Pallas Fr, radix 2^29: ni = -r^-1 mod 2^261 (digit by digit: r = 1 mod 2^29,
+// so the next digit is the negated current limb of 1 + ni * r), t = r - 2^254 (five limbs).
+struct RowConstsHost { uint32_t ni[9]; uint32_t t[5]; };
+inline RowConstsHost row_consts_host() {
+    RowConstsHost K; uint64_t T[19]; for (auto& v : T) v = 0; T[0] = 1;
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t d = (uint32_t)((0u - (uint32_t)T[i]) & FR_M29); K.ni[i] = d;
+        for (int j = 0; j < 9; ++j) T[i + j] += (uint64_t)d * fr_p29<PF>(j);
+        for (int k = i; k < 18; ++k) { T[k + 1] += T[k] >> 29; T[k] &= FR_M29; }
+    }
+    for (int k = 0; k < 5; ++k) K.t[k] = fr_p29<PF>(k);
+    return K;
+}
+
+#if defined(__HIPCC__)
+// ---- row form: one product on the 16 lanes of a DPP row -------------------------------------------------------------------------------------
+// Lane c (= lane & 15) of a row holds limb c of the value, c = 0..8, lanes 9..15 hold 0; limbs below 2^30 + 8, value below 2^258.  Four rows per
+// wave = four products per slot, all multiplied by ONE operand x whose nine limbs are wave-uniform (v_readlane -> SGPRs).
+//   product     col_c = sum_k x_k y_(c-k): 9 multiply-accumulates, the row operand shifted by row_shr:k (zero fill); column 16 = x_8 y_8 on lane 8
+//   split       three 29-bit pieces per column; the low nine limbs l (row_shr:1/2) and the high part h (row_shl:9/8/7)
+//   Montgomery  m = l * (-r^-1) mod 2^261 (the low columns of a second 9x9 product), m r = m 2^254 + m t (9x5 product and two shifts), the exact
+//               carry out of the nine low columns from columns 7 and 8; result = h + high columns + carry, pieces redistributed once more.
+// x y / 2^261 (mod r), below 2^255: what fr29_mul_mont computes on one lane, in 150 instead of ~480 instructions on the dependent chain.
+namespace row {
+constexpr uint32_t M29 = (1u << 29) - 1;
+template <int K> __device__ __forceinline__ uint32_t shr(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, true); }   // lane i <- lane i-K of its row, else 0
+template <int K> __device__ __forceinline__ uint32_t shl(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xf, 0xf, true); }   // lane i <- lane i+K of its row, else 0
+template <int K> __device__ __forceinline__ uint64_t shr64(uint64_t v) { return (uint64_t)shr<K>((uint32_t)v) | ((uint64_t)shr<K>((uint32_t)(v >> 32)) << 32); }
+template <int K> __device__ __forceinline__ uint64_t shl64(uint64_t v) { return (uint64_t)shl<K>((uint32_t)v) | ((uint64_t)shl<K>((uint32_t)(v >> 32)) << 32); }
+struct Consts { uint32_t ni[9]; uint32_t t[5]; };        // -r^-1 mod 2^261 and t = r - 2^254 in radix 2^29 (wave-uniform)
+template <int K> struct Conv {
+    static __device__ __forceinline__ void run(uint64_t& acc, const uint32_t* s, uint32_t v) { acc += (uint64_t)s[K] * shr<K>(v); Conv<K - 1>::run(acc, s, v); }
+};
+template <> struct Conv<0> { static __device__ __forceinline__ void run(uint64_t& acc, const uint32_t* s, uint32_t v) { acc += (uint64_t)s[0] * v; } };
+__device__ __forceinline__ uint32_t mul(const uint32_t* xs, uint32_t y, const Consts& K, uint32_t cidx) {
+    const uint32_t is8 = cidx == 8 ? ~0u : 0u, lt8 = cidx < 8 ? ~0u : 0u, lt9 = cidx < 9 ? ~0u : 0u, is9 = cidx == 9 ? ~0u : 0u;
+    uint64_t col = 0; Conv<8>::run(col, xs, y);
+    const uint64_t e = (uint64_t)xs[8] * (y & is8);
+    const uint32_t p0 = (uint32_t)col & M29, p1 = (uint32_t)(col >> 29) & M29, p2 = (uint32_t)(col >> 58);
+    const uint32_t e0 = (uint32_t)e & M29, e1 = (uint32_t)(e >> 29) & M29, e2 = (uint32_t)(e >> 58);
+    const uint32_t l = p0 + shr<1>(p1) + shr<2>(p2);
+    const uint32_t h = shl<9>(p0) + shl<8>(p1) + shl<7>(p2) + shl<1>(e0) + e1 + shr<1>(e2);
+    uint64_t mc = 0; Conv<8>::run(mc, K.ni, l);
+    const uint32_t m0 = (uint32_t)mc & M29, m1 = (uint32_t)(mc >> 29) & M29, m2 = (uint32_t)(mc >> 58);
+    const uint32_t ml = (m0 + shr<1>(m1) + shr<2>(m2)) & lt9;
+    uint64_t mt = 0; Conv<4>::run(mt, K.t, ml);
+    const uint32_t lo7 = (ml & 127u) << 22, hi = ml >> 7;                                      // m 2^254 = m 2^22 X^8
+    const uint64_t S = mt + l + shr<8>(lo7);                                                   // the nine low columns sum to C X^9 exactly
+    const uint64_t Q = S + shr64<1>(S >> 29);
+    const uint64_t C = ((Q + (1u << 28)) >> 29) & ((uint64_t)is8 | ((uint64_t)is8 << 32));    // on lane 8
+    const uint64_t Z = shl64<9>(mt) + h + hi + shl<1>(lo7) + shl64<8>(C);
+    const uint32_t zl = (uint32_t)Z;
+    const uint32_t z0 = zl & ((M29 & lt8) | is8), z1 = (uint32_t)(Z >> 29) & M29 & lt8, z2 = (uint32_t)(Z >> 58) & lt8;
+    return (z0 + shr<1>(z1) + shr<2>(z2) + shl<1>((zl & is9) << 29)) & lt9;
+}
+// limbs below 2^32 (a sum of a few row-form values) -> limbs below 2^29 + 8, the top limb absorbing what is above 2^232
+__device__ __forceinline__ uint32_t norm(uint32_t v, uint32_t cidx) {
+    const uint32_t lt8 = cidx < 8 ? ~0u : 0u, is8 = cidx == 8 ? ~0u : 0u;
+    return (v & ((M29 & lt8) | is8)) + shr<1>((v >> 29) & lt8);
+}
+__device__ __forceinline__ void bcast(uint32_t* xs, uint32_t v) {        // the nine limbs of row 0's value, wave-uniform
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xs[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
+}
+__device__ __forceinline__ uint32_t row1_to_row0(uint32_t v) { return (uint32_t)__builtin_amdgcn_permlane16_swap(v, v, false, false)[1]; }   // lanes 0..15 <- lanes 16..31
+__device__ __forceinline__ uint32_t row2_to_row0(uint32_t v) { return (uint32_t)__builtin_amdgcn_permlane32_swap(v, v, false, false)[1]; }   // lanes 0..15 <- lanes 32..47
+}  // namespace row
+
+// ---- the three-wave sponge ------------------------------------------------------------------------------------------------------------------------
+// LDS words behind the one-wave kernel's area (coop_lds_bytes): mailboxes of the partial rounds.  Rows of 16 words: a row-form value is written /
+// read by the 16 lanes of a DPP row as they are (lanes 9..15 carry zeros).
+struct ChainLds {
+    uint32_t* s0;      // [17][9]   state entering the partial rounds (nine 29-bit limbs, canonical)
+    uint32_t* sfin;    // [17][16]  state leaving them (lazy limbs)
+    uint32_t* y;       // [64][16]  y_q = X_q^5 (three steps by 2^261), row form, as wave A produced it
+    uint32_t* h;       // [64][16]  H_q - E_q from wave B (below 2r, limbs below 2^29)
+    uint32_t* e;       // [64][16]  E_q from wave C
+    uint32_t* ca;      // [64][64]  chain_a (wave A's row constants), copied once
+    volatile uint32_t* flag;   // [0] y_ready, [1] h_ready, [2] e_ready, [3] timeout seen — monotonic counters, + 64 per permutation
+};
+constexpr int CHAIN_WORDS = 17 * 9 + 3 + 17 * 16 + 3 * 64 * 16 + 64 * 64 + 4;
+static inline size_t chain_lds_bytes() { return coop_lds_bytes(17) + (size_t)(CHAIN_WORDS + 3) / 4 * 16; }
+constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;     // a wave waits for a wave of its own workgroup (always resident): the bound only keeps a logic error from hanging the GPU
+
+__device__ __forceinline__ bool chain_wait(volatile uint32_t* flags, int which, uint32_t target) {
+    for (uint32_t spin = 0; spin < CHAIN_SPIN_LIMIT; ++spin) {
+        if ((int32_t)(flags[which] - target) >= 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    flags[3] = 1u; return false;
+}
+__device__ __forceinline__ void chain_post(volatile uint32_t* flags, int which, uint32_t value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    flags[which] = value;
+}
+// nine lazy limbs (any value below 2^261) -> canonical fr_t
+__device__ __forceinline__ fr_t chain_canon(fr29_t v) {
+    carry29(v); lazy_reduce29<PF>(v);
+    uint32_t tt[9];
+#pragma unroll
+    for (int wd = 0; wd < 8; ++wd) {
+        const int lo = 32 * wd, i = lo / 29, sh = lo - 29 * i;
+        uint32_t x = v.l[i] >> sh;
+        if (i + 1 < 9) x |= v.l[i + 1] << (29 - sh);
+        if (29 - sh + 29 < 32 && i + 2 < 9) x |= v.l[i + 2] << (58 - sh);
+        tt[wd] = x;
+    }
+    tt[8] = 0;
+    fr_cond_sub<PF>(tt, 0u); fr_cond_sub<PF>(tt, 0u);
+    fr_t s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s.v[i] = tt[i];
+    return s;
+}
+
+// The 64 partial rounds by the three waves.  wave 0: s = its state element on entry (lanes 0..16) and on return; waves 1, 2: s unused.
+// base: 64 * (number of permutations this workgroup has completed).  Two workgroup barriers.
+__device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev& P, const ChainLds& C, const row::Consts& RK, int wave, int lane, uint32_t base) {
+    constexpr int T = 17, W = 2 * T - 1, RP = 64;
+    if (wave == 0 && lane < T) {     // lane 0 publishes X_0 = s_0 + c_0 (wave C reads only the lanes j >= 1)
+        const fr29_t u = fr29_unpack(lane == 0 ? fr_add<PF>(s, ldg(P.rc_partial)) : s);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) C.s0[9 * lane + i] = u.l[i];
+    }
+    __syncthreads();                                                                                   // #1: s0 published, the previous permutation's mailboxes are free
+    if (wave == 0) {
+        // ---- A: the chain, row form ------------------------------------------------------------------------------------------------------------
+        const uint32_t cidx = lane & 15, rw = lane >> 4;
+        uint32_t x = (rw == 0 && cidx < 9) ? C.s0[cidx] : 0u;                                        // X_0
+        uint32_t prev = 0;
+#pragma unroll 1
+        for (int q = 0; q < RP; ++q) {
+            const uint32_t kc = C.ca[q * 64 + lane];
+            uint32_t xs[9]; row::bcast(xs, x);
+            const uint32_t t1 = row::mul(xs, rw == 0 ? x : kc, RK, cidx);                             // X^2 | a X | Gamma X
+            uint32_t x2[9]; row::bcast(x2, t1);
+            const uint32_t t2 = row::mul(x2, rw == 0 ? x : t1, RK, cidx);                             // X^3 | a X^3 | Gamma X^3
+            const uint32_t t3 = row::mul(x2, t2, RK, cidx);                                           // y_q | a_q y_q | Gamma_{q+1,q} y_q
+            if (rw == 0) C.y[q * 16 + cidx] = t3;
+            if (lane == 0) chain_post(C.flag, 0, base + q + 1);
+            chain_wait(C.flag, 2, base + q + 1);                                                      // E_q: far ahead of the chain except in the first rounds
+            chain_wait(C.flag, 1, base + q + 1);                                                      // H_q - E_q: wave B had a full round for it
+            const uint32_t eq = rw == 0 ? C.e[q * 16 + cidx] : 0u, hq = rw == 0 ? C.h[q * 16 + cidx] : 0u;
+            x = row::norm(hq + eq + row::row1_to_row0(t3) + row::row2_to_row0(prev), cidx);
+            prev = t3;
+        }
+        if (rw == 0) C.sfin[cidx] = x;                                                                // s_0 after the last partial round (no constant follows)
+    } else if (wave == 1) {
+        // ---- B: H_q - E_q = sum_{p <= q-2} Gamma_{q,p} y_p on lane q ------------------------------------------------------------------------------
+        fr29_t acc; _Pragma("unroll") for (int i = 0; i < 9; ++i) acc.l[i] = 0;
+        fr29_t g; _Pragma("unroll") for (int i = 0; i < 9; ++i) g.l[i] = P.chain_g[(size_t)i * 64 + lane];
+#pragma unroll 1
+        for (int p = -2; p <= RP - 3; ++p) {
+            if (p >= 0) {
+                fr29_t gn = g;
+                if (p + 1 <= RP - 3) { _Pragma("unroll") for (int i = 0; i < 9; ++i) gn.l[i] = P.chain_g[((size_t)(p + 1) * 9 + i) * 64 + lane]; }   // next round's multipliers, in flight during the product
+                chain_wait(C.flag, 0, base + p + 1);
+                fr29_t y; _Pragma("unroll") for (int i = 0; i < 9; ++i) y.l[i] = C.y[p * 16 + i];
+                const fr29_t pr = fr29_mul_mont<PF, true>(g, y);
+                acc = add29(acc, pr); carry29(acc); lazy_reduce29<PF>(acc);
+                g = gn;
+            }
+            const int qp = p + 2;
+            if (lane == qp) { _Pragma("unroll") for (int i = 0; i < 9; ++i) C.h[qp * 16 + i] = acc.l[i]; }
+            if (lane == 0) chain_post(C.flag, 1, base + qp + 1);
+        }
+    } else {
+        // ---- C: E_q for every round, then the lanes of the state -------------------------------------------------------------------------------------
+        const int j = 1 + (lane & 15), grp = lane >> 4;
+        fr29_t sj; _Pragma("unroll") for (int i = 0; i < 9; ++i) sj.l[i] = C.s0[9 * j + i];
+#pragma unroll 1
+        for (int b = 0; b < RP / 4; ++b) {
+            const int q = 4 * b + grp;
+            fr29_t u; _Pragma("unroll") for (int i = 0; i < 9; ++i) u.l[i] = P.sparse29[9 * ((size_t)q * W + j) + i];
+            fr29_t v = fr29_mul_mont<PF, true>(u, sj);
+            v = add29(v, shfl_xor29(v, 8)); v = add29(v, shfl_xor29(v, 4)); carry29(v);
+            v = add29(v, shfl_xor29(v, 2)); v = add29(v, shfl_xor29(v, 1)); carry29(v);
+            if ((lane & 15) == 0) {
+                if (q + 1 < RP) { const fr29_t c = fr29_unpack(ldg(P.rc_partial + q + 1)); v = add29(v, c); carry29(v); }
+                lazy_reduce29<PF>(v);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) C.e[q * 16 + i] = v.l[i];
+            }
+            if (lane == 0) chain_post(C.flag, 2, base + 4 * (b + 1));
+        }
+        fr29_t acc; _Pragma("unroll") for (int i = 0; i < 9; ++i) acc.l[i] = 0;
+#pragma unroll 1
+        for (int p4 = 0; p4 < RP / 4; ++p4) {
+            const int p = 4 * p4 + grp;
+            fr29_t wv; _Pragma("unroll") for (int i = 0; i < 9; ++i) wv.l[i] = P.chain_w[((size_t)p * (T - 1) + (j - 1)) * 9 + i];
+            chain_wait(C.flag, 0, base + 4 * p4 + 4);
+            fr29_t y; _Pragma("unroll") for (int i = 0; i < 9; ++i) y.l[i] = C.y[p * 16 + i];
+            const fr29_t pr = fr29_mul_mont<PF, true>(wv, y);
+            acc = add29(acc, pr); carry29(acc);
+        }
+        acc = add29(acc, shfl_xor29(acc, 16)); acc = add29(acc, shfl_xor29(acc, 32)); carry29(acc);
+        if (grp == 0) {
+            acc = add29(acc, sj); carry29(acc);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) C.sfin[16 * j + i] = acc.l[i];
+        }
+    }
+    __syncthreads();                                                                                   // #2: sfin complete
+    if (wave == 0 && lane < T) { fr29_t v; _Pragma("unroll") for (int i = 0; i < 9; ++i) v.l[i] = C.sfin[16 * lane + i]; s = chain_canon(v); }
+}
+
+// The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of three waves per chain.  Same job description as
+// k_tr_hash_coop_multi (block b: column b, or with J.batch column b & 3 of trace b >> 2).
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_chain(PoseidonDev P, TrMultiJob J, row::Consts RK, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    CoopLds L = coop_setup<17>(lds, P);                                  // ends with a workgroup barrier
+    ChainLds C;
+    { uint32_t* w = reinterpret_cast<uint32_t*>(lds) + coop_lds_bytes(17) / 4;
+      C.s0 = w; w += 17 * 9 + 3; C.sfin = w; w += 17 * 16; C.y = w; w += 64 * 16; C.h = w; w += 64 * 16; C.e = w; w += 64 * 16; C.ca = w; w += 64 * 64; C.flag = w;
+      for (int k = threadIdx.x; k < 17 * 16 + 3 * 64 * 16; k += blockDim.x) C.sfin[k] = 0u;                 // sfin, y, h, e: the pad lanes of the 16-word rows stay zero
+      for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) C.ca[k] = P.chain_a[k];
+      if (threadIdx.x < 4) C.flag[threadIdx.x] = 0u; }
+    __syncthreads();
+    const int b = blockIdx.x, c = J.batch ? (b & 3) : (J.stride ? 0 : b);
+    const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : (J.stride ? J.fields[0] + (size_t)b * J.stride : J.fields[c]);
+    const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
+    fr_t s = (wave == 0 && lane == 16) ? J.cap : fr_zero<PF>();
+    auto fetch = [&](size_t base) -> fr_t {
+        const size_t e = base + lane;
+        if (wave == 0 && lane < 16 && e < total) return e < np ? ldg(prefix + e) : (e < np + kk ? ldg(fields + (e - np)) : ldg(suffix + (e - np - kk)));
+        return fr_zero<PF>();
+    };
+    auto permute = [&](uint32_t cbase) {
+        const int half = P.rf / 2;
+        if (wave == 0) for (int r = 0; r < half; ++r) coop_full_round<17>(s, r, L.mds, r != half - 1, P, L, lane);
+        chain_partial_rounds(s, P, C, RK, wave, lane, cbase);
+        if (wave == 0) for (int r = half; r < P.rf; ++r) coop_full_round<17>(s, r, L.mds, true, P, L, lane);
+    };
+    uint32_t cbase = 0;
+    fr_t nxt = fetch(0);
+    for (size_t base = 0; base < total; base += 16) {                    // the lazy duplex of transcript/src/lib.rs:79-88: permute only before absorbing more
+        const fr_t cur = nxt;
+        if (base + 16 < total) nxt = fetch(base + 16);                   // in flight during the permutation
+        if (base) { permute(cbase); cbase += 64; }
+        s = fr_add<PF>(s, cur);
+    }
+    permute(cbase);
+    if (wave == 0 && lane == 0) { if (C.flag[3]) s = fr_zero<PF>(); stg(out + b, s); }   // a timed-out wait (never seen) must not pass for a digest
+}
+#endif
+
+}  // namespace stark

@@ -104,7 +104,7 @@ __device__ __forceinline__ void lds_put(uint4* base, int idx, const fr_t& x) {
 }
 // LDS: x first (16-byte slots), then M as plain words, 36 B per entry (10.7 KiB for t = 17: LDS never limits the number of
 // one-wave workgroups per CU).  B_1*M is used by ONE of the eight full rounds and is read from global memory there.
-static inline size_t coop_lds_bytes(int t) { return (size_t)(t * 9 + 3) / 4 * 16 + (size_t)t * t * 9 * 4; }
+__host__ __device__ static inline size_t coop_lds_bytes(int t) { return (size_t)(t * 9 + 3) / 4 * 16 + (size_t)t * t * 9 * 4; }
 __device__ __forceinline__ void lds_get29(const uint32_t* base, int idx, uint32_t* a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) a[i] = base[9 * idx + i];
@@ -112,52 +112,57 @@ __device__ __forceinline__ void lds_get29(const uint32_t* base, int idx, uint32_
 template <int T> __device__ __forceinline__ CoopLds coop_setup(uint4* lds, const PoseidonDev& P) {
     uint32_t* m = reinterpret_cast<uint32_t*>(lds + (T * 9 + 3) / 4);
     CoopLds L{m, reinterpret_cast<uint32_t*>(lds)};
-    for (int k = threadIdx.x; k < T * T * 9; k += 64) L.mds[k] = P.mds29[k];                                    // coalesced word copies
+    for (int k = threadIdx.x; k < T * T * 9; k += blockDim.x) L.mds[k] = P.mds29[k];                            // coalesced word copies
     __syncthreads();
     return L;
+}
+
+// One full round on one wave: S-boxes on the element lanes (the result stays in nine-limb form in LDS), then the dense MDS with every row
+// split NS ways over the lanes.  s: this lane's state element (lanes 0..T-1 meaningful), updated in place.
+template <int T>
+__device__ __forceinline__ void coop_full_round(fr_t& s, int r, const uint32_t* M, const bool in_lds, const PoseidonDev& P, const CoopLds& L, int lane) {
+    constexpr int NS = 64 / T, PER = (T + NS - 1) / NS;
+    const int row = lane % T, q = lane / T;
+    const int j0 = q * PER, j1 = (j0 + PER < T) ? j0 + PER : T;
+    const bool elem = lane < T;
+    // S-box on the element lanes; the result stays in nine-limb form (below 1.01 r: a valid multiplier operand) and goes to LDS
+    // as such — no pack / conditional subtraction here, no unpack in front of each of the row segment's terms
+    if (elem) {
+        const fr29_t u = fr29_unpack(fr_add<PF>(s, ldg(P.rc_full + r * T + lane)));
+        const fr29_t x2 = fr29_sqr_mont<PF, true>(u), x4 = fr29_sqr_mont<PF, true>(x2), x5 = fr29_mul_mont<PF, true>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L.x[9 * lane + i] = x5.l[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    fr_t part = fr_zero<PF>();
+    if (q < NS && j0 < T) {
+        static_assert(PER <= fr29_max_terms<PF>(), "row segment within one carry-free run");
+        fr_wide29 acc; fr_wide29_zero(acc);
+        for (int j = j0; j < j1; ++j) {
+            uint32_t a[9];
+            if (in_lds) lds_get29(M, row * T + j, a);
+            else { _Pragma("unroll") for (int i = 0; i < 9; ++i) a[i] = P.mds_pre29[9 * (row * T + j) + i]; }
+            fr29_t xj;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) xj.l[i] = L.x[9 * j + i];
+            fr_wide29_mac_regs(acc, a, xj);
+        }
+        part = fr_wide29_reduce<PF, true>(acc);
+    }
+    fr_t tot = part;
+#pragma unroll
+    for (int k = 1; k < NS; ++k) { fr_t o = shfl_fr(part, (lane + k * T) & 63); tot = fr_add<PF>(tot, o); }
+    if (elem) s = tot;
+    __builtin_amdgcn_wave_barrier();
 }
 
 // s: this lane's state element (lanes 0..T-1 meaningful).  Returns the permuted element.
 // T = 17: rows split 3 ways (51 lanes); T = 9: 7 ways (63 lanes).
 template <int T>
 __device__ __forceinline__ fr_t coop_permute(fr_t s, const PoseidonDev& P, const CoopLds& L, int lane) {
-    constexpr int NS = 64 / T, PER = (T + NS - 1) / NS;
     const int half = P.rf / 2, w = 2 * T - 1;
-    const int row = lane % T, q = lane / T;
-    const int j0 = q * PER, j1 = (j0 + PER < T) ? j0 + PER : T;
-    const bool elem = lane < T;
-    auto full_round = [&](int r, const uint32_t* M, const bool in_lds) {
-        // S-box on the element lanes; the result stays in nine-limb form (below 1.01 r: a valid multiplier operand) and goes to LDS
-        // as such — no pack / conditional subtraction here, no unpack in front of each of the row segment's terms
-        if (elem) {
-            const fr29_t u = fr29_unpack(fr_add<PF>(s, ldg(P.rc_full + r * T + lane)));
-            const fr29_t x2 = fr29_sqr_mont<PF, true>(u), x4 = fr29_sqr_mont<PF, true>(x2), x5 = fr29_mul_mont<PF, true>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
-#pragma unroll
-            for (int i = 0; i < 9; ++i) L.x[9 * lane + i] = x5.l[i];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        fr_t part = fr_zero<PF>();
-        if (q < NS && j0 < T) {
-            static_assert(PER <= fr29_max_terms<PF>(), "row segment within one carry-free run");
-            fr_wide29 acc; fr_wide29_zero(acc);
-            for (int j = j0; j < j1; ++j) {
-                uint32_t a[9];
-                if (in_lds) lds_get29(M, row * T + j, a);
-                else { _Pragma("unroll") for (int i = 0; i < 9; ++i) a[i] = P.mds_pre29[9 * (row * T + j) + i]; }
-                fr29_t xj;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) xj.l[i] = L.x[9 * j + i];
-                fr_wide29_mac_regs(acc, a, xj);
-            }
-            part = fr_wide29_reduce<PF, true>(acc);
-        }
-        fr_t tot = part;
-#pragma unroll
-        for (int k = 1; k < NS; ++k) { fr_t o = shfl_fr(part, (lane + k * T) & 63); tot = fr_add<PF>(tot, o); }
-        if (elem) s = tot;
-        __builtin_amdgcn_wave_barrier();
-    };
+    auto full_round = [&](int r, const uint32_t* M, const bool in_lds) { coop_full_round<T>(s, r, M, in_lds, P, L, lane); };
     for (int r = 0; r < half; ++r) full_round(r, L.mds, r != half - 1);
     // Partial rounds in blocks of 4 (the algebra of permute_core, poseidon_dev.hpp), three product latencies per round:
     //   block start : all 4*(T-1) products u_{q,j}*s_j at once (lane (q, j)), butterfly-summed per round -> D_q, parked
@@ -266,12 +271,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 // Up to 4 independent long sponges in ONE launch (one block each): the four column chains of build_f0.
 // With `batch` set, block b hashes column b & 3 of trace b >> 2 (stark_deep_fri_prove_batch_dev: the 4 * B chains of B independent traces
 // in one launch — each is serial, together they fill the chip); its fields pointer comes from the device array batch[b].
-struct TrMultiJob { const fr_t* prefix[4]; int np[4]; const fr_t* suffix[4]; int ns[4]; const fr_t* fields[4]; size_t k[4]; fr_t cap; const fr_t* const* batch; };
+// With `stride` set (and batch null), block b hashes the k[0] fields at fields[0] + b * stride under tag 0 (tr_hash_dev: n equal-length sponges).
+struct TrMultiJob { const fr_t* prefix[4]; int np[4]; const fr_t* suffix[4]; int ns[4]; const fr_t* fields[4]; size_t k[4]; fr_t cap; const fr_t* const* batch; size_t stride; };
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_coop_multi(PoseidonDev P, TrMultiJob J, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
     CoopLds L = coop_setup<17>(lds, P);
-    const int lane = threadIdx.x, b = blockIdx.x, c = J.batch ? (b & 3) : b;
-    const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : J.fields[c];
+    const int lane = threadIdx.x, b = blockIdx.x, c = J.batch ? (b & 3) : (J.stride ? 0 : b);
+    const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : (J.stride ? J.fields[0] + (size_t)b * J.stride : J.fields[c]);
     const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
     fr_t s = lane == 16 ? J.cap : fr_zero<PF>();
     auto fetch = [&](size_t base) -> fr_t {                                                // this lane's element of the rate block starting at `base`

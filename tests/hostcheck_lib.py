@@ -73,6 +73,9 @@ class HostCheck:
         s = A(states).copy(); rc = self.l.hc_full_round_linear(h, which, 1 if pre else 0, P(s), C.c_size_t(s.size // (17 * 4)))
         assert rc == 0, rc; return s
 
+    def permute_chain_model(self, h, states, t=17):
+        s = A(states).copy(); rc = self.l.hc_permute_chain_model(h, P(s), C.c_size_t(s.size // (4 * t))); assert rc == 0, rc; return s
+
     def permute_dense(self, h, states, t):
         s = A(states).copy(); self.l.hc_permute_dense(h, P(s), C.c_size_t(s.size // (4 * t))); return s
 
