@@ -173,7 +173,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
 // Long serial sponges: three waves per chain (poseidon_chain.hpp) unless the option "sponge_one_wave" asks for the round-2 one-wave form.
 static int32_t launch_column_sponges(stark_ctx* ctx, stark_params* tp, const TrMultiJob& J, unsigned nblocks, fr_t* out_dev) {
     if (tp->dev.chain_a && !ctx->opt_sponge_one_wave) {
-        const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i];
+        const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i]; RK.dbg = (uint32_t)ctx->opt_sponge_debug;
         hipLaunchKernelGGL(k_tr_hash_chain, dim3(nblocks), dim3(192), chain_lds_bytes(), ctx->stream, tp->dev, J, RK, out_dev);
     } else {
         hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(nblocks), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out_dev);
@@ -325,6 +325,7 @@ int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value) {
     else if (k == "ntt_min_waves") { if (value != 2 && value != 4) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_min_waves: 2 or 4"); ctx->opt_ntt_min_waves = (int)value; }
     else if (k == "poseidon_lane_only") ctx->opt_poseidon_lane_only = value != 0;
     else if (k == "sponge_one_wave") ctx->opt_sponge_one_wave = value != 0;
+    else if (k == "sponge_debug") ctx->opt_sponge_debug = (int)value;
     else return ctx->fail(STARK_ERR_INVALID_ARG, "unknown option '" + k + "' (ntt_direct_max_log, ntt_log_tile, ntt_min_waves, poseidon_lane_only)");
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     stark::ntt_plans_free(ctx);                  // plans (and their direct tables) are rebuilt lazily under the new options

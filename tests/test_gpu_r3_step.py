@@ -160,3 +160,23 @@ def test_handles_outlive_their_context(oracle):
     assert lib.stark_fri_state_free(st) == 0
     assert lib.stark_merkle_free(t) == 0
     assert lib.stark_poseidon_params_free(p) == 0            # the last handle: the context is released here
+
+
+@pytest.mark.parametrize("k,n", [(0, 3), (1, 2), (15, 2), (16, 2), (17, 3), (127, 2), (128, 3), (129, 1), (1000, 5), (4096 + 7, 2)])
+def test_three_wave_sponge_equals_oracle_and_one_wave_kernel(gpu_ctx, oracle, k, n):
+    """tr_hash_fields_tagged (crates/deep_ali/src/fri.rs:28-35) over n streams of k fields: from 128 fields on the library runs the three-wave
+    kernel (poseidon_chain.hpp: partial rounds unrolled, dependent chain in row form, helper waves), below that and with the option
+    "sponge_one_wave" the round-2 one-wave kernel.  Both equal the oracle at every length around the rate-16 block boundaries."""
+    import numpy as np
+    fields = oracle.synth_column(4242 + k, 3, 0, max(1, k * n))[:k * n]
+    want = np.stack([oracle.tr_hash_fields_tagged(b"ALI/S", fields[i * k:(i + 1) * k]) for i in range(n)])
+    lib = gpu_ctx.lib
+    got = {}
+    for one_wave in (0, 1):
+        gpu_ctx._chk(lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", one_wave))
+        out = np.zeros((n, 4), np.uint64)
+        buf = np.ascontiguousarray(fields if k * n else np.zeros((1, 4), np.uint64))
+        gpu_ctx._chk(lib.stark_tr_hash_fields_tagged(gpu_ctx.h, None, b"ALI/S", buf.ctypes.data_as(C.c_void_p), k, n, out.ctypes.data_as(C.c_void_p)))
+        got[one_wave] = out
+    gpu_ctx._chk(lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", 0))
+    assert (got[0] == want).all() and (got[1] == want).all()
