@@ -10,6 +10,7 @@
 #include "poseidon_pair.hpp"
 #include "poseidon_coop.hpp"
 #include "poseidon_chain.hpp"
+#include "poseidon_wave.hpp"
 #include "fri_dev.hpp"
 
 using namespace stark;
@@ -464,6 +465,14 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* 
     if (use_pair(ctx, p->dev.t)) {
         if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds2<17>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(17), st, p->dev, J, in0, in1, out);
         else hipLaunchKernelGGL(k_hash_ds2<9>, dim3((unsigned)((J.n_out + 63) / 64)), dim3(128), pair_lds_bytes(9), st, p->dev, J, in0, in1, out);
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
+    if (!ctx->opt_poseidon_lane_only && (p->dev.t == 33 || p->dev.t == 65 || p->dev.t == 129) && J.n_out <= 0x7fffffffu) {
+        // wide states (arity 32 / 64 / 128): one wave per node (poseidon_wave.hpp) — a lane per node walks a 17 ms permutation alone
+        const dim3 grid((unsigned)J.n_out), blk(64); const size_t lds = wave_lds_bytes(p->dev.t);
+        if (p->dev.t == 33) hipLaunchKernelGGL(k_hash_ds_wave<33>, grid, blk, lds, st, p->dev, J, in0, in1, out);
+        else if (p->dev.t == 65) hipLaunchKernelGGL(k_hash_ds_wave<65>, grid, blk, lds, st, p->dev, J, in0, in1, out);
+        else hipLaunchKernelGGL(k_hash_ds_wave<129>, grid, blk, lds, st, p->dev, J, in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     const int block = poseidon_block(p->dev.t);
