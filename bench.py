@@ -289,6 +289,7 @@ def main():
         if args.e2e_log:
             sections[f"prove_end_to_end_2^{args.e2e_log}"] = dict(prove(args.e2e_log, False), note="build_f0 = the four serial column sponges (fri.rs:548-557), n0/16 dependent permutations each, one wave per column")
         sections["prove_given_f0_2^20"] = dict(prove(20, True), note="deep_fri_prove stages after build_f0 on n0 = 2^20")
+        sections["serial_sponge"] = sponge_section(ctx, torch, dev)
         sections["reference_bench"] = reference_bench(ctx, np, args.csv, world)
         sections["reference_bench_presets"] = preset_bench(ctx, np, torch, dev, args.csv, world)
 
@@ -324,6 +325,28 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def sponge_section(ctx, torch, dev):
+    """The serial column sponge of build_f0 (crates/deep_ali/src/fri.rs:548-557) on its own: one tr_hash_fields_tagged over 2^14 fields (1 026
+    dependent t = 17 permutations), three-wave kernel (poseidon_chain.hpp) and the round-2 one-wave kernel (option sponge_one_wave); equal digests."""
+    lib = ctx.lib
+    n = 1 << 14
+    col = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    ctx._chk(lib.stark_synth_column_dev(ctx.h, 0x5EED0000 + 14, 0, 0, n, C.c_void_p(col.data_ptr())))
+    res, dig = {}, {}
+    for name, opt in (("three_wave", 0), ("one_wave", 1)):
+        ctx._chk(lib.stark_ctx_set_option(ctx.h, b"sponge_one_wave", opt))
+        out = torch.zeros((1, 4), dtype=torch.int64, device=dev)
+        for _ in range(2):
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
+            ctx._chk(lib.stark_tr_hash_fields_tagged_dev(ctx.h, None, b"ALI/A", C.c_void_p(col.data_ptr()), n, 1, C.c_void_p(out.data_ptr())))
+            torch.cuda.synchronize(dev); dt = time.perf_counter() - t0
+        res[name + "_us_per_permutation"] = dt * 1e6 / (n // 16 + 2); dig[name] = out.cpu().numpy().tobytes()
+    ctx._chk(lib.stark_ctx_set_option(ctx.h, b"sponge_one_wave", 0))
+    res["equal_digests"] = dig["three_wave"] == dig["one_wave"]
+    res["note"] = "one workgroup of three waves per chain: the dependent products in row form (16 lanes per product), the accumulators on two helper waves; floor of the chain 64 x 3 x 251 ns = 48 us"
+    return res
 
 
 PUBLISHED_PROOF_BYTES = {11: 39592, 12: 52000, 13: 60968, 14: 72936, 15: 87736, 16: 101976, 17: 119952, 18: 140032}   # crates/channel/benchmarkdata.csv:2-9
@@ -497,6 +520,8 @@ def cpu_baseline(np, log_n_gpu):
     res.update({"value": one["rows_per_s"], "cores": 1,
                 "sample": f"2^11-row trace x 4 columns (LDE to 2^14, merge, FRI build), {one['seconds']:.1f} s on one host core",
                 "workload_1t": one, "workload_all_cores": dict(workload(11, ncores), cores=ncores)})
+    if ncores >= 8:   # a larger sample of the same workload on all cores (about 8x the work of the one-thread sample): the CPU side at a size nearer the GPU's
+        res["workload_all_cores_2^14"] = dict(workload(14, ncores), cores=ncores, rows=1 << 14)
     res["prove"] = [prove(12, 1), prove(12, ncores), prove(16, ncores)]
     res["ntt"] = [ntt(20, 1), ntt(20, ncores), ntt(24, ncores)]
     # the serial column sponge on ONE host core (it does not parallelise): dense rounds as in the reference (oracle) and the

@@ -32,7 +32,10 @@ namespace stark {
 template <int T> struct PairCfg {
     static constexpr int NXD = T == 17 ? 3 : 2;        // X's share of the lanes in the per-round dot products: lanes 1..NXD (X's sums stay
                                                        // <= 7 terms: no carry pass in the S-box chain; Y takes the other lanes)
-    static constexpr int NXU = (T - 1) / 2;            // X updates lanes 1..NXU, Y lanes NXU+1..T-1
+#ifndef STARK_NXU17
+#define STARK_NXU17 8
+#endif
+    static constexpr int NXU = T == 17 ? STARK_NXU17 : (T - 1) / 2;   // X updates lanes 1..NXU, Y lanes NXU+1..T-1
     static constexpr int NX = (T - 1) / 2;             // full rounds: X owns elements 0..NX-1 (S-box, absorb), Y the rest
     static constexpr int EXTRA = 3;                    // slots beyond the state: x mailboxes 1..3
     __host__ __device__ static constexpr int xslot(int p) { return p == 0 ? 0 : T + (p - 1); }

@@ -1,20 +1,33 @@
 #!/bin/bash
-# tools/gpu_session.sh — one gpurun call: parity tests, instruction rates, kernel timings, bench, rocprof stats.
+# tools/gpu_session.sh — THE reproducible GPU session of a round (one gpurun call, about 12 GPU-minutes):
+#   /usr/local/graft/bin/gpurun --timeout 1190 -- 'bash tools/gpu_session.sh r03'
+# 1. the whole `-m gpu` suite; 2. the bench line (+ the reference-schema CSV); 3. rocprofv3 kernel stats of the timed steps only;
+# 4. the counter passes, each --pmc set in its own run (HBM bytes of the 2^23 coset NTT; SQ counters of the hot kernels);
+# 5. the serial-sponge timings (three-wave against one-wave kernel, where a permutation's time goes) and the product-chain micro-benchmarks;
+# 6. a two-rank rehearsal of `bench.py --gpus 2` on the one GPU (gloo).
+# Everything lands in gpurun_out/ with the round tag; tools/pmc_summary.py turns the counter CSVs into the tracked summaries under profiles/.
 set -o pipefail
 mkdir -p gpurun_out
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-R=${1:-r01}
-mkdir -p tools/bin
-[ -x tools/bin/instr_rates ] || hipcc --offload-arch=gfx950 -O3 tools/instr_rates.hip -o tools/bin/instr_rates
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_$R.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/gpu_tests_$R.log
-tail -3 gpurun_out/gpu_tests_$R.log
-timeout -k 10 120 ./tools/bin/instr_rates > gpurun_out/instr_rates_$R.jsonl 2>&1 && echo "instr_rates done" &&
-timeout -k 10 300 python tests/gpu_microbench.py > gpurun_out/microbench_$R.jsonl 2>&1 && echo "microbench done" && cat gpurun_out/microbench_$R.jsonl &&
-timeout -k 10 400 python bench.py --steps 2 --warmup 1 > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err && echo "bench done" && cat gpurun_out/bench_$R.json &&
-(cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -- python3 $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/rocprof_bench_$R.log 2>&1; echo "rocprof exit $?") &&
-(mkdir -p gpurun_out/prof_$R && find /tmp/prof_$R -name "*stats*.csv" -exec cp {} gpurun_out/prof_$R/ \; ; ls gpurun_out/prof_$R) &&
-(cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f_$R -- python3 $OLDPWD/tools/ntt_once.py 23 2 > $OLDPWD/gpurun_out/pmc_fetch_$R.log 2>&1; echo "pmc fetch exit $?") &&
-(cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$R -- python3 $OLDPWD/tools/ntt_once.py 23 2 > $OLDPWD/gpurun_out/pmc_write_$R.log 2>&1; echo "pmc write exit $?") &&
-(mkdir -p gpurun_out/pmc_$R && find /tmp/pmc_f_$R /tmp/pmc_w_$R -name "*counter_collection*.csv" -exec sh -c 'cp "$1" gpurun_out/pmc_'$R'/$(echo "$1" | tr / _ | tail -c 60)' _ {} \; ; ls gpurun_out/pmc_$R) &&
-(STARK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 1 --warmup 1 --log-trace 16 > gpurun_out/bench2_gloo_$R.json 2> gpurun_out/bench2_gloo_$R.err; echo "bench2 exit $?"; cat gpurun_out/bench2_gloo_$R.json | cut -c1-300)
+R=${1:-rXX}
+OUT=$PWD/gpurun_out
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/gpu_tests_$R.log 2>&1; rc=$?; echo "tests exit $rc"; tail -14 $OUT/gpu_tests_$R.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 500 python bench.py --steps 10 --warmup 2 --csv $OUT/benchmarkdata_$R.csv > $OUT/bench_$R.json 2> $OUT/bench_$R.err; rc=$?; echo "bench exit $rc"; cut -c1-400 $OUT/bench_$R.json; tail -3 $OUT/bench_$R.err
+[ $rc -eq 0 ] || exit $rc
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -- python3 $OUT/../bench.py --steps-only --steps 3 --warmup 1 > $OUT/rocprof_bench_$R.log 2>&1; echo "rocprof stats exit $?") &&
+(mkdir -p $OUT/prof_$R && find /tmp/prof_$R -name "*stats*.csv" -exec cp {} $OUT/prof_$R/ \; ; ls $OUT/prof_$R)
+pmc() {  # name, counters, what
+  (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d /tmp/pmc_$1_$R -- python3 $OUT/../tools/kern_once.py $3 2 > $OUT/pmc_$1_$R.log 2>&1; echo "pmc $1 exit $?")
+  f=$(find /tmp/pmc_$1_$R -name "*counter_collection*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/pmc_$1_$R.csv && wc -l $OUT/pmc_$1_$R.csv
+}
+pmc fetch "FETCH_SIZE" ntt &&
+pmc write "WRITE_SIZE" ntt &&
+pmc sqa "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES" all &&
+pmc sqb "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" all
+timeout -k 10 200 python tools/sponge_timing.py 2>/dev/null | grep log_n0 > $OUT/sponge_timing_$R.jsonl; cat $OUT/sponge_timing_$R.jsonl
+timeout -k 10 200 python tools/sponge_debug_timing.py 2>/dev/null | grep dbg > $OUT/sponge_breakdown_$R.jsonl
+[ -x tools/bin/chain_row ] && (cd tools && ./bin/chain_row 2000 > $OUT/chain_row_$R.txt && python3 chain_row_check.py $OUT/chain_row_$R.txt | tail -1; ./bin/chain_bench > $OUT/chain_bench_$R.txt 2>&1)
+(STARK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 1 --warmup 1 --log-trace 16 --no-cpu-baseline > $OUT/bench2_gloo_$R.json 2> $OUT/bench2_gloo_$R.err; echo "bench2 exit $?"; cut -c1-300 $OUT/bench2_gloo_$R.json)
+echo "session done"

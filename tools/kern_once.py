@@ -1,6 +1,7 @@
 """tools/kern_once.py — runs the hot kernels a fixed number of times each, nothing else of weight, for counter profiling
 (rocprofv3 --pmc ... -- python3 tools/kern_once.py):  k_ntt_strided x2 + k_ntt_last (2^23 coset NTT), k_leaf_pair2 (2^22 leaves),
-k_hash_ds2<17> (one arity-16 level over 2^22 digests).  Usage: kern_once.py [ntt|leaf|tree|all] [reps]"""
+k_hash_ds2<17> (one arity-16 level over 2^22 digests), k_tr_hash_chain (one serial sponge over 2^14 fields: the three-wave kernel).
+Usage: kern_once.py [ntt|leaf|tree|sponge|all] [reps]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,3 +33,10 @@ if what in ("leaf", "tree", "all"):
         for _ in range(reps):
             ctx._chk(lib.stark_poseidon_hash_ds_batch_dev(ctx.h, p17.h, 16, 0, 0, 0, P(f), n, P(out)))
 ctx.sync(); ctx.close()
+
+if what in ("sponge", "all"):
+    n = 1 << 14
+    col = torch.empty((n, 4), dtype=torch.int64, device=dev); out = torch.empty((1, 4), dtype=torch.int64, device=dev)
+    ctx._chk(lib.stark_synth_column_dev(ctx.h, 1, 2, 0, n, P(col)))
+    for _ in range(reps):
+        ctx._chk(lib.stark_tr_hash_fields_tagged_dev(ctx.h, None, b"ALI/A", P(col), n, 1, P(out)))
