@@ -306,6 +306,12 @@ int32_t stark_ntt_rows_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, s
  *            dst[i][m] = w_n^(k1 m) * sum_k' src[i][k'] shift^(k' R + k1) w_C^(k' m).  src is not modified (all cosets of an LDE start from it);
  *            the second phase is a plain size-R transform over k1 after ONE exchange — no exchange between inverse and forward. */
 int32_t stark_ntt_rows_coset_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* src, uint64_t* dst, size_t nrows, size_t log_cols, size_t row0, size_t log_n, const uint64_t* shift4);
+/*   stark_lde_sharded_dev: the whole LDE of ONE column block-sharded over the ranks of the context's communicator (stark_comm_init; one rank without a
+ *            communicator is allowed): rank q passes its natural-order block of 2^log_n / W evaluations and receives its block of the 2^(log_n+log_blowup)
+ *            evaluations on shift * <w_N> — the composition of the building blocks above with FOUR all-to-alls, inside the library, so that a host
+ *            without Python (the reference's Rust process) drives a multi-GPU LDE with one call per column.  (dist.py's ShardedLde is the same
+ *            composition in Python and stays the form the CPU gloo tests exercise.) */
+int32_t stark_lde_sharded_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* block, size_t log_n, size_t log_blowup, const uint64_t* shift4, uint64_t* out);
 int32_t stark_ntt_columns_coset_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, const uint64_t* shift4);
 int32_t stark_permute3_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t d0, size_t d1, size_t d2, int32_t p0, int32_t p1, int32_t p2);
 int32_t stark_interleave_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t n, size_t stride, size_t offset);

@@ -411,6 +411,11 @@ pub mod comm {
     use super::*;
     pub fn unique_id() -> [u8; STARK_COMM_ID_BYTES] { let mut id = [0u8; STARK_COMM_ID_BYTES]; let rc = unsafe { stark_comm_unique_id(id.as_mut_ptr()) }; assert_eq!(rc, STARK_OK, "RCCL unavailable"); id }
     pub fn init(ctx: &Ctx, nranks: i32, rank: i32, id: &[u8; STARK_COMM_ID_BYTES]) { ctx.chk(unsafe { stark_comm_init(ctx.raw(), nranks, rank, id.as_ptr()) }); }
+    /// The LDE of one column of a trace block-sharded over the ranks (this rank's natural-order block in, its block of the extended column out):
+    /// four exchanges inside the library — what a multi-GPU `build_f0` front end calls once per column.
+    pub unsafe fn lde_sharded_dev(ctx: &Ctx, field_id: i32, block: *const u64, log_n: usize, log_blowup: usize, shift: &[u64; 4], out: *mut u64) {
+        ctx.chk(stark_lde_sharded_dev(ctx.raw(), field_id, block, log_n, log_blowup, shift.as_ptr(), out));
+    }
     pub unsafe fn all_to_all_dev(ctx: &Ctx, send: *const c_void, recv: *mut c_void, bytes_per_peer: usize) { ctx.chk(stark_comm_all_to_all_dev(ctx.raw(), send, recv, bytes_per_peer)); }
     pub unsafe fn all_gather_dev(ctx: &Ctx, send: *const c_void, recv: *mut c_void, bytes: usize) { ctx.chk(stark_comm_all_gather_dev(ctx.raw(), send, recv, bytes)); }
 }

@@ -267,8 +267,69 @@ static int32_t rows_coset_run(stark_ctx* ctx, const fr_t* src, fr_t* dst, uint64
     return STARK_OK;
 }
 
+// ---- one column of a trace block-sharded over the ranks of the context's communicator: the LDE as ONE call (dist.py ShardedLde in C++) ----------
+// A host without Python composes nothing: rank q passes its natural-order block [q n/W, (q+1) n/W) of the 2^log_n evaluations and receives its block of the
+// 2^(log_n + log_blowup) evaluations on shift * <w_N>.  Four all-to-alls (stark_comm_all_to_all_dev; a device copy when there is one rank and no
+// communicator), whatever the blow-up: natural rows -> column blocks; the inverse transform's transpose; ONE exchange for the first-phase outputs of all
+// cosets; ONE to natural blocks.  Between them only local phases (columns_run, ntt_run rows, rows_coset_run) and the pack kernel.
+static int32_t pack3(stark_ctx* ctx, const fr_t* src, fr_t* dst, uint64_t d0, uint64_t d1, uint64_t d2, int p0, int p1, int p2) {
+    const uint64_t d[3] = {d0, d1, d2}, st[3] = {d1 * d2, d2, 1}; const int pm[3] = {p0, p1, p2};
+    const uint64_t tot = d0 * d1 * d2; if (!tot) return STARK_OK;
+    hipLaunchKernelGGL(k_permute3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, src, dst, d[pm[0]], d[pm[1]], d[pm[2]], st[pm[0]], st[pm[1]], st[pm[2]]);
+    STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+}
+static int32_t exchange(stark_ctx* ctx, int W, const fr_t* send, fr_t* recv, size_t elems_per_peer) {
+    if (W == 1 && !ctx->comm) { STARK_HIP(ctx, hipMemcpyAsync(recv, send, elems_per_peer * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream)); return STARK_OK; }
+    return stark_comm_all_to_all_dev(ctx, send, recv, elems_per_peer * sizeof(fr_t));
+}
+template <class F>
+static int32_t lde_sharded_run(stark_ctx* ctx, const fr_t* block, int log_n, int lb, const fr_t& shift, fr_t* out) {
+    const int W = ctx->comm ? stark_comm_size(ctx) : 1, rank = ctx->comm ? stark_comm_rank(ctx) : 0;
+    if (log_n < 2 || log_n + lb > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "lde_sharded: sizes");
+    const int log_rows = std::min(10, log_n / 2), log_cols = log_n - log_rows;
+    const uint64_t R = 1ull << log_rows, Cc = 1ull << log_cols, b = 1ull << lb;
+    if (W < 1 || (W & (W - 1)) || R % W || Cc % W) return ctx->fail(STARK_ERR_INVALID_ARG, "lde_sharded: the ranks must divide the 2^log_rows x 2^log_cols view");
+    const uint64_t nrl = R / W, ncl = Cc / W, nl = nrl * Cc;               // local rows, local columns, local elements of one size-n vector
+    DevBuf t0, t1, big0, big1;
+    STARK_HIP(ctx, t0.alloc(ctx, nl * sizeof(fr_t))); STARK_HIP(ctx, t1.alloc(ctx, nl * sizeof(fr_t)));
+    STARK_HIP(ctx, big0.alloc(ctx, b * nl * sizeof(fr_t))); STARK_HIP(ctx, big1.alloc(ctx, b * nl * sizeof(fr_t)));
+    // 1. natural row block [nrl][W][ncl] -> [W][nrl][ncl]; exchange -> the column block [R][ncl]
+    STARK_TRY(pack3(ctx, block, t0.fr(), nrl, W, ncl, 1, 0, 2));
+    STARK_TRY(exchange(ctx, W, t0.fr(), t1.fr(), nrl * ncl));
+    // 2. inverse six-step transform: column phase + twiddle, its transpose, row phase with n^-1
+    STARK_TRY((columns_run<F>(ctx, t1.fr(), log_rows, ncl, (uint64_t)rank * ncl, log_n, true)));
+    STARK_TRY(exchange(ctx, W, t1.fr(), t0.fr(), nrl * ncl));
+    STARK_TRY(pack3(ctx, t0.fr(), t1.fr(), W, nrl, ncl, 1, 0, 2));                                   // [nrl][C]: rows k1 of c[k1 + R k']
+    { DevBuf sc; const fr_t ninv = x32<F>(fr_inv<F>(fr_from_u64<F>(1ull << log_n)));
+      STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &ninv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+      STARK_TRY((ntt_run<F>(ctx, t1.fr(), log_cols, nrl, true, nullptr, sc.fr())));
+      STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }                                           // the scale word is freed on leaving this scope
+    // 3. first phase of every coset transform on that same slab (nothing is exchanged between the inverse and the forward transforms)
+    const fr_t wN = fr_root_of_unity<F>((unsigned)(log_n + lb)); fr_t sh = shift;
+    for (uint64_t s_ = 0; s_ < b; ++s_) { STARK_TRY((rows_coset_run<F>(ctx, t1.fr(), big0.fr() + s_ * nl, nrl, log_cols, (uint64_t)rank * nrl, log_n, sh))); sh = fr_mul<F>(sh, wN); }
+    // 4. ONE exchange for all cosets: [b nrl][W][ncl] -> [W][b nrl][ncl]; then [W][b][nrl ncl] -> [b][R][ncl] -> [b ncl][R]; size-R transforms
+    STARK_TRY(pack3(ctx, big0.fr(), big1.fr(), b * nrl, W, ncl, 1, 0, 2));
+    STARK_TRY(exchange(ctx, W, big1.fr(), big0.fr(), b * nrl * ncl));
+    STARK_TRY(pack3(ctx, big0.fr(), big1.fr(), W, b, nrl * ncl, 1, 0, 2));
+    STARK_TRY(pack3(ctx, big1.fr(), big0.fr(), b, R, ncl, 0, 2, 1));
+    STARK_TRY((ntt_run<F>(ctx, big0.fr(), log_rows, b * ncl, false, nullptr, nullptr)));
+    // 5. ONE exchange to natural blocks of the interleaved result out[(K2 C + K1) b + s]: [b][ncl][R] -> [R][ncl][b]; exchange; [W][nrl][ncl b] -> [nrl][W][ncl b]
+    STARK_TRY(pack3(ctx, big0.fr(), big1.fr(), b, ncl, R, 2, 1, 0));
+    STARK_TRY(exchange(ctx, W, big1.fr(), big0.fr(), nrl * ncl * b));
+    STARK_TRY(pack3(ctx, big0.fr(), out, W, nrl, ncl * b, 1, 0, 2));
+    return STARK_OK;
+}
+
 extern "C" {
 
+int32_t stark_lde_sharded_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* block, size_t log_n, size_t log_blowup, const uint64_t* shift4, uint64_t* out) {
+    if (!ctx || !block || !out || !shift4 || block == out) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const fr_t sh = load_fr(shift4);
+    if (field_id == STARK_FIELD_PALLAS_FR) return lde_sharded_run<PallasFr>(ctx, as_fr(block), (int)log_n, (int)log_blowup, sh, as_fr(out));
+    if (field_id == STARK_FIELD_BLS12_381_FR) return lde_sharded_run<Bls12381Fr>(ctx, as_fr(block), (int)log_n, (int)log_blowup, sh, as_fr(out));
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
 int32_t stark_ntt_rows_coset_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* src, uint64_t* dst, size_t nrows, size_t log_cols, size_t row0, size_t log_n, const uint64_t* shift4) {
     if (!ctx || !src || !dst || !shift4 || src == dst) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));

@@ -162,6 +162,7 @@ __device__ __forceinline__ void lds_vstore(volatile uint32_t* p, uint32_t v) { *
 __device__ __forceinline__ bool chain_wait(volatile uint32_t* flags, int which, uint32_t target) {
     for (uint32_t spin = 0; spin < CHAIN_SPIN_LIMIT; ++spin) {
         if ((int32_t)(lds_vload(flags + which) - target) >= 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+        if ((spin & 4095u) == 4095u && lds_vload(flags + 3)) return false;       // another wait has already timed out: do not queue up behind it
         __builtin_amdgcn_s_sleep(1);
     }
     lds_vstore(flags + 3, 1u); return false;

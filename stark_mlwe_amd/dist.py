@@ -236,6 +236,12 @@ class HipProvider:
         """First local phase of a forward coset transform on the inverse's transposed output (stark_ntt_rows_coset_dev): src -> out."""
         self._run(self.lib.stark_ntt_rows_coset_dev, self.ctx.h, self.field, self._p(src), self._p(out), nrows, log_cols, row0, log_n, _npp(shift4))
 
+    def lde_sharded(self, block, log_n, log_blowup, shift4):
+        """The whole sharded LDE of one column inside the library (stark_lde_sharded_dev): its exchanges run on the library's communicator."""
+        out = torch.empty((block.shape[0] << log_blowup, 4), dtype=torch.int64, device=block.device)
+        self._run(self.lib.stark_lde_sharded_dev, self.ctx.h, self.field, self._p(block), log_n, log_blowup, _npp(shift4), self._p(out))
+        return out
+
     def permute3(self, src, dims, perm):
         """Contiguous [dims[perm[0]], dims[perm[1]], dims[perm[2]], 4] copy of the [d0][d1][d2] array `src` (hand-written pack kernel)."""
         out = torch.empty((dims[perm[0]] * dims[perm[1]] * dims[perm[2]], 4), dtype=torch.int64, device=src.device)
@@ -451,6 +457,11 @@ class ShardedLde:
         return self.inv._perm(t, dims, perm)
 
     def __call__(self, block: torch.Tensor) -> torch.Tensor:
+        if hasattr(self.p, "lde_sharded") and (isinstance(_COMM, LibComm) or self.W == 1) and self.inv.log_rows == min(10, self.log_n // 2):
+            # the same composition inside the library (one C-ABI call per column, what a host without Python uses); its four exchanges go through
+            # the library's communicator, so this route needs LibComm (or a single rank)
+            STATS["all_to_all"] += self.n_all_to_all
+            return self.p.lde_sharded(block.contiguous(), self.log_n, self.lb, self.shifts[0])
         b, W, inv = 1 << self.lb, self.W, self.inv
         R, Cc, nrl, ncl = inv.R, inv.C, inv.nrl, inv.ncl
         coeff = inv.forward(inv.from_natural_blocks(block), self.ninv)                     # exchanges 1, 2: [R/W][C] = c[k1 + R k'], k1 local

@@ -180,3 +180,27 @@ def test_three_wave_sponge_equals_oracle_and_one_wave_kernel(gpu_ctx, oracle, k,
         got[one_wave] = out
     gpu_ctx._chk(lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", 0))
     assert (got[0] == want).all() and (got[1] == want).all()
+
+
+@pytest.mark.parametrize("field,log_n,lb", [(0, 4, 1), (0, 12, 3), (0, 16, 3), (0, 21, 2), (1, 13, 3)])
+def test_library_sharded_lde_one_rank_equals_single_gpu_lde(gpu_ctx, oracle, field, log_n, lb):
+    """stark_lde_sharded_dev (the multi-GPU LDE as ONE C-ABI call: four exchanges inside the library) on a single rank without a communicator equals
+    stark_lde_dev, and at small sizes the oracle's LDE; both fields.  (N > 1 runs the same code with RCCL exchanges — unmeasured, see INTEGRATION.md.)"""
+    import numpy as np
+    import torch
+    from stark_mlwe_amd.api import _ptr
+    n = 1 << log_n
+    x = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    if field == 0:
+        gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, 77 + log_n, 1, 0, n, C.c_void_p(x.data_ptr())))
+        host = x.cpu().numpy().view(np.uint64)
+    else:
+        host = np.stack([oracle.from_int(pow(3, i + 1, 2**61 - 1) * 0x9E3779B97F4A7C15, field=1) for i in range(n)]) if log_n <= 13 else None
+        x.copy_(torch.from_numpy(host.view(np.int64)))
+    shift = oracle.from_u64(5 if field == 0 else 7, field)
+    a = torch.empty((n << lb, 4), dtype=torch.int64, device="cuda"); b = torch.empty_like(a)
+    gpu_ctx._chk(gpu_ctx.lib.stark_lde_sharded_dev(gpu_ctx.h, field, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(a.data_ptr())))
+    gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, field, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(b.data_ptr())))
+    assert bool((a == b).all())
+    if log_n <= 13:
+        assert (a.cpu().numpy().view(np.uint64) == oracle.lde(field, host, lb, shift)).all()
