@@ -147,9 +147,11 @@ struct ChainLds {
     uint32_t* e;       // [64][16]  E_q from wave C
     uint32_t* ca;      // [64][64]  chain_a (wave A's row constants), copied once
     uint32_t* fmail;   // [2][17][8] full rounds: the partial row sums of waves B and C
+    uint32_t* rcf;     // [8][17][8] the full rounds' constants and
+    uint32_t* mpre;    // [17*17][9] B_1 M of the last first-half round, copied once: no global-memory latency on the chain
     volatile uint32_t* flag;   // [0] y_ready, [1] h_ready, [2] e_ready, [3] timeout seen — monotonic counters, + 64 per permutation
 };
-constexpr int CHAIN_WORDS = 17 * 9 + 3 + 17 * 16 + 3 * 64 * 16 + 64 * 64 + 2 * 17 * 8 + 4;
+constexpr int CHAIN_WORDS = 17 * 9 + 3 + 17 * 16 + 3 * 64 * 16 + 64 * 64 + 2 * 17 * 8 + 8 * 17 * 8 + 17 * 17 * 9 + 3 + 4;
 __host__ __device__ static inline size_t chain_base_bytes() { return (coop_lds_bytes(17) + 63) / 64 * 64; }      // mailbox rows are read 16 bytes at a time
 static inline size_t chain_lds_bytes() { return chain_base_bytes() + (size_t)(CHAIN_WORDS + 3) / 4 * 16; }
 constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;     // a wave waits for a wave of its own workgroup (always resident): the bound only keeps a logic error from hanging the GPU
@@ -202,20 +204,21 @@ __device__ __forceinline__ fr_t chain_canon(fr29_t v) {
 __device__ __forceinline__ void chain_full_round(fr_t& s, int r, const bool in_lds, const PoseidonDev& P, const CoopLds& L, const ChainLds& C, int wave, int lane) {
     constexpr int T = 17;
     if (wave == 0 && lane < T) {
-        const fr29_t u = fr29_unpack(fr_add<PF>(s, ldg(P.rc_full + r * T + lane)));
+        fr_t rc; _Pragma("unroll") for (int i = 0; i < 8; ++i) rc.v[i] = C.rcf[(r * T + lane) * 8 + i];
+        const fr29_t u = fr29_unpack(fr_add<PF>(s, rc));
         const fr29_t x2 = fr29_sqr_mont<PF, true>(u), x4 = fr29_sqr_mont<PF, true>(x2), x5 = fr29_mul_mont<PF, true>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
 #pragma unroll
         for (int i = 0; i < 9; ++i) L.x[9 * lane + i] = x5.l[i];
     }
     __syncthreads();
+    const uint32_t* M = in_lds ? L.mds : C.mpre;
     const int row = lane % T, q = lane / T, g = 3 * wave + q, j0 = 2 * g, j1 = (j0 + 2 < T) ? j0 + 2 : T;
     fr_t part = fr_zero<PF>();
     if (q < 3 && j0 < T) {
         fr_wide29 acc; fr_wide29_zero(acc);
         for (int j = j0; j < j1; ++j) {
             uint32_t a[9];
-            if (in_lds) lds_get29(L.mds, row * T + j, a);
-            else { _Pragma("unroll") for (int i = 0; i < 9; ++i) a[i] = P.mds_pre29[9 * (row * T + j) + i]; }
+            lds_get29(M, row * T + j, a);
             fr29_t xj;
 #pragma unroll
             for (int i = 0; i < 9; ++i) xj.l[i] = L.x[9 * j + i];
@@ -238,7 +241,21 @@ __device__ __forceinline__ void chain_full_round(fr_t& s, int r, const bool in_l
 
 // The 64 partial rounds by the three waves.  wave 0: s = its state element on entry (lanes 0..16) and on return; waves 1, 2: s unused.
 // base: 64 * (number of permutations this workgroup has completed).  Two workgroup barriers.
-__device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev& P, const ChainLds& C, const row::Consts& RK, int wave, int lane, uint32_t base) {
+// The first multipliers each helper wave needs are the same in every permutation: loaded ONCE per kernel (ChainPre), so that no global-memory latency
+// stands between the barrier that opens the partial rounds and the first E_q.
+struct ChainPre { fr29_t first; fr29_t first2; };      // wave B: Gamma_{lane,0}; wave C: u_{grp,j} of batch 0 and w_{grp,j} of slot 0
+__device__ __forceinline__ ChainPre chain_preload(const PoseidonDev& P, int wave, int lane) {
+    constexpr int T = 17, W = 2 * T - 1;
+    ChainPre pre; _Pragma("unroll") for (int i = 0; i < 9; ++i) { pre.first.l[i] = 0; pre.first2.l[i] = 0; }
+    if (wave == 1) { _Pragma("unroll") for (int i = 0; i < 9; ++i) pre.first.l[i] = P.chain_g[(size_t)i * 64 + lane]; }
+    if (wave == 2) {
+        const int j = 1 + (lane & 15), grp = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { pre.first.l[i] = P.sparse29[9 * ((size_t)grp * W + j) + i]; pre.first2.l[i] = P.chain_w[((size_t)grp * (T - 1) + (j - 1)) * 9 + i]; }
+    }
+    return pre;
+}
+__device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev& P, const ChainLds& C, const row::Consts& RK, const ChainPre& pre, int wave, int lane, uint32_t base) {
     constexpr int T = 17, W = 2 * T - 1, RP = 64;
     if (wave == 0 && lane < T) {     // lane 0 publishes X_0 = s_0 + c_0 (wave C reads only the lanes j >= 1)
         const fr29_t u = fr29_unpack(lane == 0 ? fr_add<PF>(s, ldg(P.rc_partial)) : s);
@@ -279,7 +296,7 @@ __device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev&
     } else if (wave == 1) {
         // ---- B: H_q - E_q = sum_{p <= q-2} Gamma_{q,p} y_p on lane q ------------------------------------------------------------------------------
         fr29_t acc; _Pragma("unroll") for (int i = 0; i < 9; ++i) acc.l[i] = 0;
-        fr29_t g; _Pragma("unroll") for (int i = 0; i < 9; ++i) g.l[i] = P.chain_g[(size_t)i * 64 + lane];
+        fr29_t g = pre.first;
 #pragma unroll 1
         for (int p = -2; p <= RP - 3; ++p) {
             if (p >= 0) {
@@ -301,7 +318,7 @@ __device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev&
         // ---- C: E_q for every round, then the lanes of the state -------------------------------------------------------------------------------------
         const int j = 1 + (lane & 15), grp = lane >> 4;
         fr29_t sj; _Pragma("unroll") for (int i = 0; i < 9; ++i) sj.l[i] = C.s0[9 * j + i];
-        fr29_t un; _Pragma("unroll") for (int i = 0; i < 9; ++i) un.l[i] = P.sparse29[9 * ((size_t)grp * W + j) + i];
+        fr29_t un = pre.first;
 #pragma unroll 1
         for (int b = 0; b < RP / 4; ++b) {
             const int q = 4 * b + grp;
@@ -319,7 +336,7 @@ __device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev&
             if (lane == 0) chain_post(C.flag, 2, base + 4 * (b + 1));
         }
         fr29_t acc; _Pragma("unroll") for (int i = 0; i < 9; ++i) acc.l[i] = 0;
-        fr29_t wn; _Pragma("unroll") for (int i = 0; i < 9; ++i) wn.l[i] = P.chain_w[((size_t)grp * (T - 1) + (j - 1)) * 9 + i];
+        fr29_t wn = pre.first2;
 #pragma unroll 1
         for (int p4 = 0; p4 < RP / 4; ++p4) {
             const int p = 4 * p4 + grp;
@@ -351,14 +368,17 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2))
     CoopLds L = coop_setup<17>(lds, P);                                  // ends with a workgroup barrier
     ChainLds C;
     { uint32_t* w = reinterpret_cast<uint32_t*>(lds) + chain_base_bytes() / 4;
-      C.s0 = w; w += 17 * 9 + 3; C.sfin = w; w += 17 * 16; C.y = w; w += 64 * 16; C.h = w; w += 64 * 16; C.e = w; w += 64 * 16; C.ca = w; w += 64 * 64; C.fmail = w; w += 2 * 17 * 8; C.flag = w;
+      C.s0 = w; w += 17 * 9 + 3; C.sfin = w; w += 17 * 16; C.y = w; w += 64 * 16; C.h = w; w += 64 * 16; C.e = w; w += 64 * 16; C.ca = w; w += 64 * 64; C.fmail = w; w += 2 * 17 * 8; C.rcf = w; w += 8 * 17 * 8; C.mpre = w; w += 17 * 17 * 9 + 3; C.flag = w;
       for (int k = threadIdx.x; k < 17 * 16 + 3 * 64 * 16; k += blockDim.x) C.sfin[k] = 0u;                 // sfin, y, h, e: the pad lanes of the 16-word rows stay zero
       for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) C.ca[k] = P.chain_a[k];
+      { const uint32_t* rc = reinterpret_cast<const uint32_t*>(P.rc_full); for (int k = threadIdx.x; k < 8 * 17 * 8; k += blockDim.x) C.rcf[k] = rc[k]; }
+      for (int k = threadIdx.x; k < 17 * 17 * 9; k += blockDim.x) C.mpre[k] = P.mds_pre29[k];
       if (threadIdx.x < 4) lds_vstore(C.flag + threadIdx.x, 0u); }
     __syncthreads();
     const int b = blockIdx.x, c = J.batch ? (b & 3) : (J.stride ? 0 : b);
     const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : (J.stride ? J.fields[0] + (size_t)b * J.stride : J.fields[c]);
     const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
+    const ChainPre pre = chain_preload(P, wave, lane);
     fr_t s = (wave == 0 && lane == 16) ? J.cap : fr_zero<PF>();
     auto fetch = [&](size_t base) -> fr_t {
         const size_t e = base + lane;
@@ -368,7 +388,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2))
     auto permute = [&](uint32_t cbase) {
         const int half = P.rf / 2;
         if (!(RK.dbg & 8)) for (int r = 0; r < half; ++r) chain_full_round(s, r, r != half - 1, P, L, C, wave, lane);
-        if (!(RK.dbg & 16)) chain_partial_rounds(s, P, C, RK, wave, lane, cbase);
+        if (!(RK.dbg & 16)) chain_partial_rounds(s, P, C, RK, pre, wave, lane, cbase);
         if (!(RK.dbg & 8)) for (int r = half; r < P.rf; ++r) chain_full_round(s, r, true, P, L, C, wave, lane);
     };
     uint32_t cbase = 0;
