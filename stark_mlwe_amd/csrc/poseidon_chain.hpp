@@ -87,7 +87,7 @@ inline RowConstsHost row_consts_host() {
 //   split       three 29-bit pieces per column; the low nine limbs l (row_shr:1/2) and the high part h (row_shl:9/8/7)
 //   Montgomery  m = l * (-r^-1) mod 2^261 (the low columns of a second 9x9 product), m r = m 2^254 + m t (9x5 product and two shifts), the exact
 //               carry out of the nine low columns from columns 7 and 8; result = h + high columns + carry, pieces redistributed once more.
-// x y / 2^261 (mod r), below 2^255: what fr29_mul_mont computes on one lane, in 150 instead of ~480 instructions on the dependent chain.
+// x y / 2^261 (mod r), below 2^255: what fr29_mul_mont computes on one lane, in ~125 instead of ~480 instructions on the dependent chain.
 namespace row {
 constexpr uint32_t M29 = (1u << 29) - 1;
 template <int K> __device__ __forceinline__ uint32_t shr(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, true); }   // lane i <- lane i-K of its row, else 0
@@ -107,21 +107,25 @@ __device__ __forceinline__ uint32_t mul(const uint32_t* xs, uint32_t y, const Co
     uint64_t col = 0; Conv<8>::run(col, xs, y);
     const uint64_t e = (uint64_t)xs[8] * (y & is8);
     const uint32_t p0 = (uint32_t)col & M29, p1 = (uint32_t)(col >> 29) & M29, p2 = (uint32_t)(col >> 58);
-    const uint32_t e0 = (uint32_t)e & M29, e1 = (uint32_t)(e >> 29) & M29, e2 = (uint32_t)(e >> 58);
+    const uint32_t e0 = (uint32_t)e & M29, e1 = (uint32_t)(e >> 29);                          // top limbs are below 2^26: column 16 is below 2^52
     const uint32_t l = keep(p0 + shr<1>(p1)) + shr<2>(p2);
-    const uint32_t h = keep(keep(keep(keep(e1 + shl<9>(p0)) + shl<8>(p1)) + shl<7>(p2)) + shl<1>(e0)) + shr<1>(e2);
+    const uint32_t h = keep(keep(keep(e1 + shl<9>(p0)) + shl<8>(p1)) + shl<7>(p2)) + shl<1>(e0);
     uint64_t mc = 0; Conv<8>::run(mc, K.ni, l);
     const uint32_t m0 = (uint32_t)mc & M29, m1 = (uint32_t)(mc >> 29) & M29, m2 = (uint32_t)(mc >> 58);
     const uint32_t ml = (keep(m0 + shr<1>(m1)) + shr<2>(m2)) & lt9;
     uint64_t mt = 0; Conv<4>::run(mt, K.t, ml);
+    // from here on everything fits 32 bits: the columns of m t are split into pieces like the others
+    const uint32_t t0 = (uint32_t)mt & M29, t1 = (uint32_t)(mt >> 29) & M29, t2 = (uint32_t)(mt >> 58);
     const uint32_t lo7 = (ml & 127u) << 22, hi = ml >> 7;                                      // m 2^254 = m 2^22 X^8
-    const uint64_t S = mt + l + shr<8>(lo7);                                                   // the nine low columns sum to C X^9 exactly
-    const uint64_t Q = S + shr64<1>(S >> 29);
-    const uint64_t C = ((Q + (1u << 28)) >> 29) & ((uint64_t)is8 | ((uint64_t)is8 << 32));    // on lane 8
-    const uint64_t Z = shl64<9>(mt) + h + hi + shl<1>(lo7) + shl64<8>(C);
-    const uint32_t zl = (uint32_t)Z;
-    const uint32_t z0 = zl & ((M29 & lt8) | is8), z1 = (uint32_t)(Z >> 29) & M29 & lt8, z2 = (uint32_t)(Z >> 58) & lt8;
-    return (keep(keep(z0 + shr<1>(z1)) + shr<2>(z2)) + shl<1>((zl & is9) << 29)) & lt9;
+    // the nine low limbs of V + m r (below 2^31.4 each) sum to C X^9 exactly, C <= 8: limbs 0..6 contribute less than 2^-25 to C X - (s_8 + floor(s_7 / X)),
+    // an integer in {0, 1} — so C = (s_8 + floor(s_7 / X) + X - 1) >> 29
+    const uint32_t sl = keep(keep(keep(l + t0) + shr<1>(t1)) + shr<2>(t2)) + shr<8>(lo7);
+    const uint32_t Q = sl + shr<1>(sl >> 29);
+    const uint32_t Cc = ((Q + M29) >> 29) & is8;                                               // on lane 8
+    // high part, below 2^32: h + the high columns of m t and m 2^254 + the carry (brought from lane 8 to lane 0)
+    const uint32_t Z = keep(keep(keep(keep(keep(h + hi) + shl<1>(lo7)) + shl<9>(t0)) + shl<8>(t1)) + shl<7>(t2)) + shl<8>(Cc);
+    const uint32_t z0 = Z & ((M29 & lt8) | is8), z1 = (Z >> 29) & lt8;
+    return (keep(z0 + shr<1>(z1)) + shl<1>((Z & is9) << 29)) & lt9;                            // limbs below 2^29 + 8; the top limb keeps what is above 2^232
 }
 // limbs below 2^32 (a sum of a few row-form values) -> limbs below 2^29 + 8, the top limb absorbing what is above 2^232
 __device__ __forceinline__ uint32_t norm(uint32_t v, uint32_t cidx) {

@@ -44,14 +44,14 @@ __device__ __forceinline__ u32 mulrow(const u32* xs, u32 y, const RowConsts& K, 
     const u32 m0 = (u32)mc & M29, m1 = (u32)(mc >> 29) & M29, m2 = (u32)(mc >> 58);
     const u32 ml = (m0 + shr<1>(m1) + shr<2>(m2)) & lt9;
     u64 mt = 0; Conv<4>::run(mt, K.t, ml);
-    const u32 lo7 = (ml & 127u) << 22, hi = ml >> 7;                                          // m * 2^254 = m * 2^22 * X^8
-    const u64 S = mt + l + shr<8>(lo7);                                                       // the nine low columns sum to C * X^9 exactly
-    const u64 Q = S + shr64<1>(S >> 29);
-    const u64 C = ((Q + (1u << 28)) >> 29) & ((u64)is8 | ((u64)is8 << 32));                   // lane 8
-    const u64 Z = shl64<9>(mt) + h + hi + shl<1>(lo7) + shl64<8>(C);
-    const u32 zl = (u32)Z;
-    const u32 z0 = zl & ((M29 & lt8) | is8), z1 = (u32)(Z >> 29) & M29 & lt8, z2 = (u32)(Z >> 58) & lt8;
-    return (z0 + shr<1>(z1) + shr<2>(z2) + shl<1>((zl & is9) << 29)) & lt9;
+    const u32 t0 = (u32)mt & M29, t1 = (u32)(mt >> 29) & M29, t2 = (u32)(mt >> 58);            // from here on everything fits 32 bits
+    const u32 lo7 = (ml & 127u) << 22, hi = ml >> 7;                                           // m * 2^254 = m * 2^22 * X^8
+    const u32 sl = l + t0 + shr<1>(t1) + shr<2>(t2) + shr<8>(lo7);                             // the nine low limbs sum to C * X^9 exactly, C <= 8
+    const u32 Q = sl + shr<1>(sl >> 29);
+    const u32 Cc = ((Q + M29) >> 29) & is8;                                                    // lane 8
+    const u32 Z = h + hi + shl<1>(lo7) + shl<9>(t0) + shl<8>(t1) + shl<7>(t2) + shl<8>(Cc);
+    const u32 z0 = Z & ((M29 & lt8) | is8), z1 = (Z >> 29) & lt8;
+    return (z0 + shr<1>(z1) + shl<1>((Z & is9) << 29)) & lt9;
 }
 
 __global__ void __launch_bounds__(64) k_chain_row(const u32* in, u32* out, RowConsts K, int iters) {
