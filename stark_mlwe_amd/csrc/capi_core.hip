@@ -175,7 +175,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
 static int32_t launch_column_sponges(stark_ctx* ctx, stark_params* tp, const TrMultiJob& J, unsigned nblocks, fr_t* out_dev) {
     if (tp->dev.chain_a && !ctx->opt_sponge_one_wave) {
         const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i]; RK.dbg = (uint32_t)ctx->opt_sponge_debug;
-        hipLaunchKernelGGL(k_tr_hash_chain, dim3(nblocks), dim3(192), chain_lds_bytes(), ctx->stream, tp->dev, J, RK, out_dev);
+        hipLaunchKernelGGL(k_tr_hash_chain, dim3(nblocks), dim3(320), chain_lds_bytes(), ctx->stream, tp->dev, J, RK, out_dev);
     } else {
         hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(nblocks), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out_dev);
     }
@@ -268,6 +268,7 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     (void)hipFuncSetAttribute((const void*)k_leaf_pair2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_hash_ds2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_hash_ds2<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_tr_hash_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     *out = c; return STARK_OK;
 }
 }  // extern "C"

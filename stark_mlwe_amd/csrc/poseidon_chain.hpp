@@ -136,6 +136,14 @@ __device__ __forceinline__ void bcast(uint32_t* xs, uint32_t v) {        // the 
 #pragma unroll
     for (int k = 0; k < 9; ++k) xs[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
 }
+// the nine limbs of EVERY row's own value, each row's lanes receiving their row's (ds_swizzle, bit-mask mode: lane <- (lane & 0x10) | k inside each
+// group of 32 lanes): the broadcast operand of a product whose two factors both differ from row to row (the S-boxes of the full rounds)
+template <int K> __device__ __forceinline__ uint32_t rowlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (K << 5)); }
+__device__ __forceinline__ void bcast_rows(uint32_t* xs, uint32_t v) {
+    xs[0] = rowlane<0>(v); xs[1] = rowlane<1>(v); xs[2] = rowlane<2>(v); xs[3] = rowlane<3>(v); xs[4] = rowlane<4>(v);
+    xs[5] = rowlane<5>(v); xs[6] = rowlane<6>(v); xs[7] = rowlane<7>(v); xs[8] = rowlane<8>(v);
+}
+__device__ __forceinline__ uint32_t mulg(uint32_t a, uint32_t b, const Consts& K, uint32_t cidx) { uint32_t xs[9]; bcast_rows(xs, a); return mul(xs, b, K, cidx); }
 __device__ __forceinline__ uint32_t row1_to_row0(uint32_t v) { return (uint32_t)__builtin_amdgcn_permlane16_swap(v, v, false, false)[1]; }   // lanes 0..15 <- lanes 16..31
 __device__ __forceinline__ uint32_t row2_to_row0(uint32_t v) { return (uint32_t)__builtin_amdgcn_permlane32_swap(v, v, false, false)[1]; }   // lanes 0..15 <- lanes 32..47
 }  // namespace row
@@ -144,18 +152,21 @@ __device__ __forceinline__ uint32_t row2_to_row0(uint32_t v) { return (uint32_t)
 // LDS words behind the one-wave kernel's area (coop_lds_bytes): mailboxes of the partial rounds.  Rows of 16 words: a row-form value is written /
 // read by the 16 lanes of a DPP row as they are (lanes 9..15 carry zeros).
 struct ChainLds {
-    uint32_t* s0;      // [17][9]   state entering the partial rounds (nine 29-bit limbs, canonical)
-    uint32_t* sfin;    // [17][16]  state leaving them (lazy limbs)
+    uint32_t* s0;      // [17][16]  state entering the partial rounds (lazy limbs below 2^29 + 8, values below 11 r)
+    uint32_t* sfin;    // [17][16]  state leaving them (values below 2 r)
     uint32_t* y;       // [64][16]  y_q = X_q^5 (three steps by 2^261), row form, as wave A produced it
     uint32_t* h;       // [64][16]  H_q - E_q from wave B (below 2r, limbs below 2^29)
     uint32_t* e;       // [64][16]  E_q from wave C
     uint32_t* ca;      // [64][64]  chain_a (wave A's row constants), copied once
-    uint32_t* fmail;   // [2][17][8] full rounds: the partial row sums of waves B and C
-    uint32_t* rcf;     // [8][17][8] the full rounds' constants and
+    uint32_t* x;       // [17][16]  full rounds: the S-box outputs
+    uint32_t* pm;      // [3][17][16] full rounds: the row sums of waves 0..2 (lazy nine-limb partials)
+    uint32_t* in;      // [16][16]  the rate block being absorbed, nine limbs per field
+    uint32_t* rc29;    // [8][17][16] the full rounds' constants as nine limbs and
     uint32_t* mpre;    // [17*17][9] B_1 M of the last first-half round, copied once: no global-memory latency on the chain
+    uint32_t* rcp0;    // [16]      the first partial round's constant, nine limbs
     volatile uint32_t* flag;   // [0] y_ready, [1] h_ready, [2] e_ready, [3] timeout seen — monotonic counters, + 64 per permutation
 };
-constexpr int CHAIN_WORDS = 17 * 9 + 3 + 17 * 16 + 3 * 64 * 16 + 64 * 64 + 2 * 17 * 8 + 8 * 17 * 8 + 17 * 17 * 9 + 3 + 4;
+constexpr int CHAIN_WORDS = 2 * 17 * 16 + 3 * 64 * 16 + 64 * 64 + 17 * 16 + 3 * 17 * 16 + 16 * 16 + 8 * 17 * 16 + 17 * 17 * 9 + 3 + 16 + 4;
 __host__ __device__ static inline size_t chain_base_bytes() { return (coop_lds_bytes(17) + 63) / 64 * 64; }      // mailbox rows are read 16 bytes at a time
 static inline size_t chain_lds_bytes() { return chain_base_bytes() + (size_t)(CHAIN_WORDS + 3) / 4 * 16; }
 constexpr uint32_t CHAIN_SPIN_LIMIT = 1u << 22;     // a wave waits for a wave of its own workgroup (always resident): the bound only keeps a logic error from hanging the GPU
@@ -202,49 +213,42 @@ __device__ __forceinline__ fr_t chain_canon(fr29_t v) {
     return s;
 }
 
-// One full round by the three waves: the 17 S-boxes on wave A (three dependent one-lane products: nothing to share), then the dense product with every
-// row cut into NINE segments of two terms, three per wave (poseidon_coop.hpp cuts it into three of six on one wave): the row sums' share of a full
-// round drops from ~2.5 us to ~1 us.  Two workgroup barriers.  s: wave A's state element (lanes 0..16), updated in place.
-__device__ __forceinline__ void chain_full_round(fr_t& s, int r, const bool in_lds, const PoseidonDev& P, const CoopLds& L, const ChainLds& C, int wave, int lane) {
+// State between the rounds of a sponge: ROW FORM on five waves — element e on row e & 3 of wave e >> 2, limb c on lane c of the row, lazily reduced
+// (limbs below 2^31, values below 11 r), never canonical inside a sponge.
+// One full round: all 17 S-boxes at once in row form, both factors of every product a row's own (three products of ~135 instructions + one LDS-crossbar
+// broadcast each, against three one-lane products of ~190-230: 0.85 against 1.7 us); the dense rows on waves 0..2 as before (nine two-term
+// segments, wide accumulation, one Montgomery step per segment), left as lazy nine-limb partials that the rows add up themselves.  Two barriers.
+__device__ __forceinline__ void chain_full_round(uint32_t& sr, int r, const bool in_lds, const CoopLds& L, const ChainLds& C, const row::Consts& RK, int wave, int lane) {
     constexpr int T = 17;
-    if (wave == 0 && lane < T) {
-        fr_t rc; _Pragma("unroll") for (int i = 0; i < 8; ++i) rc.v[i] = C.rcf[(r * T + lane) * 8 + i];
-        const fr29_t u = fr29_unpack(fr_add<PF>(s, rc));
-        const fr29_t x2 = fr29_sqr_mont<PF, true>(u), x4 = fr29_sqr_mont<PF, true>(x2), x5 = fr29_mul_mont<PF, true>(u, x4);     // x^5 / 2^20: the matrices carry the 2^20
-#pragma unroll
-        for (int i = 0; i < 9; ++i) L.x[9 * lane + i] = x5.l[i];
+    const uint32_t cidx = lane & 15; const int e = 4 * wave + (lane >> 4); const bool valid = e < T;
+    {
+        const uint32_t u = row::norm(sr + (valid ? C.rc29[(r * T + e) * 16 + cidx] : 0u), cidx);
+        const uint32_t x2 = row::mulg(u, u, RK, cidx), x4 = row::mulg(x2, x2, RK, cidx), x5 = row::mulg(u, x4, RK, cidx);      // three steps by 2^261: x^5 / 2^20, as fr_pow5_r29
+        if (valid) C.x[e * 16 + cidx] = x5;
     }
     __syncthreads();
-    const uint32_t* M = in_lds ? L.mds : C.mpre;
-    const int row = lane % T, q = lane / T, g = 3 * wave + q, j0 = 2 * g, j1 = (j0 + 2 < T) ? j0 + 2 : T;
-    fr_t part = fr_zero<PF>();
-    if (q < 3 && j0 < T) {
-        fr_wide29 acc; fr_wide29_zero(acc);
-        for (int j = j0; j < j1; ++j) {
-            uint32_t a[9];
-            lds_get29(M, row * T + j, a);
-            fr29_t xj;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) xj.l[i] = L.x[9 * j + i];
-            fr_wide29_mac_regs(acc, a, xj);
+    if (wave < 3) {
+        const uint32_t* M = in_lds ? L.mds : C.mpre;
+        const int row = lane % T, q = lane / T, g = 3 * wave + q, j0 = 2 * g, j1 = (j0 + 2 < T) ? j0 + 2 : T;
+        fr29_t part; _Pragma("unroll") for (int i = 0; i < 9; ++i) part.l[i] = 0;
+        if (q < 3 && j0 < T) {
+            fr_wide29 acc; fr_wide29_zero(acc);
+            for (int j = j0; j < j1; ++j) {
+                uint32_t a[9]; lds_get29(M, row * T + j, a);
+                fr29_t xj; chain_read_row(C.x + j * 16, xj);
+                fr_wide29_mac_regs(acc, a, xj);
+            }
+            fr_wide29_mont<PF, true>(acc, part.l);
         }
-        part = fr_wide29_reduce<PF, true>(acc);
-    }
-    fr_t tot = part;
+        fr29_t tot = part;
 #pragma unroll
-    for (int k = 1; k < 3; ++k) { fr_t o = shfl_fr(part, (lane + k * T) & 63); tot = fr_add<PF>(tot, o); }
-    if (wave != 0 && lane < T) { _Pragma("unroll") for (int i = 0; i < 8; ++i) C.fmail[((wave - 1) * T + lane) * 8 + i] = tot.v[i]; }
+        for (int k = 1; k < 3; ++k) tot = add29(tot, shfl29(part, (lane + k * T) & 63));
+        if (lane < T) { carry29(tot); _Pragma("unroll") for (int i = 0; i < 9; ++i) C.pm[(wave * T + lane) * 16 + i] = tot.l[i]; }
+    }
     __syncthreads();
-    if (wave == 0 && lane < T) {
-        fr_t b, c;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { b.v[i] = C.fmail[lane * 8 + i]; c.v[i] = C.fmail[(T + lane) * 8 + i]; }
-        s = fr_add<PF>(fr_add<PF>(tot, b), c);
-    }
+    sr = valid ? C.pm[e * 16 + cidx] + C.pm[(T + e) * 16 + cidx] + C.pm[(2 * T + e) * 16 + cidx] : 0u;
 }
 
-// The 64 partial rounds by the three waves.  wave 0: s = its state element on entry (lanes 0..16) and on return; waves 1, 2: s unused.
-// base: 64 * (number of permutations this workgroup has completed).  Two workgroup barriers.
 // The first multipliers each helper wave needs are the same in every permutation: loaded ONCE per kernel (ChainPre), so that no global-memory latency
 // stands between the barrier that opens the partial rounds and the first E_q.
 struct ChainPre { fr29_t first; fr29_t first2; };      // wave B: Gamma_{lane,0}; wave C: u_{grp,j} of batch 0 and w_{grp,j} of slot 0
@@ -259,18 +263,16 @@ __device__ __forceinline__ ChainPre chain_preload(const PoseidonDev& P, int wave
     }
     return pre;
 }
-__device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev& P, const ChainLds& C, const row::Consts& RK, const ChainPre& pre, int wave, int lane, uint32_t base) {
+__device__ __forceinline__ void chain_partial_rounds(uint32_t& sr, const PoseidonDev& P, const ChainLds& C, const row::Consts& RK, const ChainPre& pre, int wave, int lane, uint32_t base) {
     constexpr int T = 17, W = 2 * T - 1, RP = 64;
-    if (wave == 0 && lane < T) {     // lane 0 publishes X_0 = s_0 + c_0 (wave C reads only the lanes j >= 1)
-        const fr29_t u = fr29_unpack(lane == 0 ? fr_add<PF>(s, ldg(P.rc_partial)) : s);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) C.s0[9 * lane + i] = u.l[i];
-    }
+    const uint32_t cidx = lane & 15; const int e = 4 * wave + (lane >> 4); const bool valid = e < T;
+    const uint32_t s_norm = row::norm(sr, cidx);
+    if (valid) C.s0[e * 16 + cidx] = s_norm;                                                          // the state entering the partial rounds, for wave C (elements 1..16)
     __syncthreads();                                                                                   // #1: s0 published, the previous permutation's mailboxes are free
     if (wave == 0) {
         // ---- A: the chain, row form ------------------------------------------------------------------------------------------------------------
-        const uint32_t cidx = lane & 15, rw = lane >> 4;
-        uint32_t x = (rw == 0 && cidx < 9) ? C.s0[cidx] : 0u;                                        // X_0
+        const uint32_t rw = lane >> 4;
+        uint32_t x = rw == 0 ? row::norm(s_norm + C.rcp0[cidx], cidx) : 0u;                           // X_0 = s_0 + c_0: element 0 lives on this wave's row 0
         uint32_t prev = 0;
 #pragma unroll 1
         for (int q = 0; q < RP; ++q) {
@@ -318,10 +320,10 @@ __device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev&
             if (lane == qp) { _Pragma("unroll") for (int i = 0; i < 9; ++i) C.h[qp * 16 + i] = acc.l[i]; }
             if (lane == 0) chain_post(C.flag, 1, base + qp + 1);
         }
-    } else {
+    } else if (wave == 2) {
         // ---- C: E_q for every round, then the lanes of the state -------------------------------------------------------------------------------------
         const int j = 1 + (lane & 15), grp = lane >> 4;
-        fr29_t sj; _Pragma("unroll") for (int i = 0; i < 9; ++i) sj.l[i] = C.s0[9 * j + i];
+        fr29_t sj; chain_read_row(C.s0 + 16 * j, sj);
         fr29_t un = pre.first;
 #pragma unroll 1
         for (int b = 0; b < RP / 4; ++b) {
@@ -355,45 +357,51 @@ __device__ __forceinline__ void chain_partial_rounds(fr_t& s, const PoseidonDev&
         }
         acc = add29(acc, shfl_xor29(acc, 16)); acc = add29(acc, shfl_xor29(acc, 32)); carry29(acc);
         if (grp == 0) {
-            acc = add29(acc, sj); carry29(acc);
+            acc = add29(acc, sj); carry29(acc); lazy_reduce29<PF>(acc);                                // 64 products and the old lane: below 76 r -> below 2 r
 #pragma unroll
             for (int i = 0; i < 9; ++i) C.sfin[16 * j + i] = acc.l[i];
         }
     }
     __syncthreads();                                                                                   // #2: sfin complete
-    if (wave == 0 && lane < T) { fr29_t v; _Pragma("unroll") for (int i = 0; i < 9; ++i) v.l[i] = C.sfin[16 * lane + i]; s = chain_canon(v); }
+    sr = valid ? C.sfin[e * 16 + cidx] : 0u;
 }
 
 // The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of three waves per chain.  Same job description as
 // k_tr_hash_coop_multi (block b: column b, or with J.batch column b & 3 of trace b >> 2).
-__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_chain(PoseidonDev P, TrMultiJob J, row::Consts RK, fr_t* __restrict__ out) {
+__global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_chain(PoseidonDev P, TrMultiJob J, row::Consts RK, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     CoopLds L = coop_setup<17>(lds, P);                                  // ends with a workgroup barrier
     ChainLds C;
     { uint32_t* w = reinterpret_cast<uint32_t*>(lds) + chain_base_bytes() / 4;
-      C.s0 = w; w += 17 * 9 + 3; C.sfin = w; w += 17 * 16; C.y = w; w += 64 * 16; C.h = w; w += 64 * 16; C.e = w; w += 64 * 16; C.ca = w; w += 64 * 64; C.fmail = w; w += 2 * 17 * 8; C.rcf = w; w += 8 * 17 * 8; C.mpre = w; w += 17 * 17 * 9 + 3; C.flag = w;
-      for (int k = threadIdx.x; k < 17 * 16 + 3 * 64 * 16; k += blockDim.x) C.sfin[k] = 0u;                 // sfin, y, h, e: the pad lanes of the 16-word rows stay zero
+      C.s0 = w; w += 17 * 16; C.sfin = w; w += 17 * 16; C.y = w; w += 64 * 16; C.h = w; w += 64 * 16; C.e = w; w += 64 * 16; C.x = w; w += 17 * 16; C.pm = w; w += 3 * 17 * 16;
+      C.in = w; w += 16 * 16; C.rc29 = w; w += 8 * 17 * 16; C.ca = w; w += 64 * 64; C.mpre = w; w += 17 * 17 * 9 + 3; C.rcp0 = w; w += 16; C.flag = w;
+      for (int k = threadIdx.x; k < 2 * 17 * 16 + 3 * 64 * 16 + 17 * 16 + 3 * 17 * 16 + 16 * 16; k += blockDim.x) C.s0[k] = 0u;      // s0 .. in: the pad lanes of the 16-word rows stay zero
+      for (int k = threadIdx.x; k < 8 * 17; k += blockDim.x) { const fr29_t u = fr29_unpack(P.rc_full[k]); for (int i = 0; i < 16; ++i) C.rc29[k * 16 + i] = i < 9 ? u.l[i] : 0u; }
       for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) C.ca[k] = P.chain_a[k];
-      { const uint32_t* rc = reinterpret_cast<const uint32_t*>(P.rc_full); for (int k = threadIdx.x; k < 8 * 17 * 8; k += blockDim.x) C.rcf[k] = rc[k]; }
       for (int k = threadIdx.x; k < 17 * 17 * 9; k += blockDim.x) C.mpre[k] = P.mds_pre29[k];
+      if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(P.rc_partial[0]); for (int i = 0; i < 16; ++i) C.rcp0[i] = i < 9 ? u.l[i] : 0u; }
       if (threadIdx.x < 4) lds_vstore(C.flag + threadIdx.x, 0u); }
     __syncthreads();
     const int b = blockIdx.x, c = J.batch ? (b & 3) : (J.stride ? 0 : b);
     const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : (J.stride ? J.fields[0] + (size_t)b * J.stride : J.fields[c]);
     const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
     const ChainPre pre = chain_preload(P, wave, lane);
-    fr_t s = (wave == 0 && lane == 16) ? J.cap : fr_zero<PF>();
+    const uint32_t cidx = lane & 15; const int e = 4 * wave + (lane >> 4); const bool valid = e < 17;
+    // the state in row form; element 16 starts as the capacity constant
+    if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(J.cap); for (int i = 0; i < 9; ++i) C.sfin[16 * 16 + i] = u.l[i]; }
+    __syncthreads();
+    uint32_t sr = valid ? C.sfin[e * 16 + cidx] : 0u;
     auto fetch = [&](size_t base) -> fr_t {
-        const size_t e = base + lane;
-        if (wave == 0 && lane < 16 && e < total) return e < np ? ldg(prefix + e) : (e < np + kk ? ldg(fields + (e - np)) : ldg(suffix + (e - np - kk)));
+        const size_t q = base + lane;
+        if (wave == 0 && lane < 16 && q < total) return q < np ? ldg(prefix + q) : (q < np + kk ? ldg(fields + (q - np)) : ldg(suffix + (q - np - kk)));
         return fr_zero<PF>();
     };
     auto permute = [&](uint32_t cbase) {
         const int half = P.rf / 2;
-        if (!(RK.dbg & 8)) for (int r = 0; r < half; ++r) chain_full_round(s, r, r != half - 1, P, L, C, wave, lane);
-        if (!(RK.dbg & 16)) chain_partial_rounds(s, P, C, RK, pre, wave, lane, cbase);
-        if (!(RK.dbg & 8)) for (int r = half; r < P.rf; ++r) chain_full_round(s, r, true, P, L, C, wave, lane);
+        if (!(RK.dbg & 8)) for (int r = 0; r < half; ++r) chain_full_round(sr, r, r != half - 1, L, C, RK, wave, lane);
+        if (!(RK.dbg & 16)) chain_partial_rounds(sr, P, C, RK, pre, wave, lane, cbase);
+        if (!(RK.dbg & 8)) for (int r = half; r < P.rf; ++r) chain_full_round(sr, r, true, L, C, RK, wave, lane);
     };
     uint32_t cbase = 0;
     fr_t nxt = fetch(0);
@@ -401,10 +409,19 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2))
         const fr_t cur = nxt;
         if (base + 16 < total) nxt = fetch(base + 16);                   // in flight during the permutation
         if (base) { permute(cbase); cbase += 64; }
-        s = fr_add<PF>(s, cur);
+        if (wave == 0 && lane < 16) { const fr29_t u = fr29_unpack(cur); _Pragma("unroll") for (int i = 0; i < 9; ++i) C.in[lane * 16 + i] = u.l[i]; }
+        __syncthreads();
+        if (e < 16) sr += C.in[e * 16 + cidx];                            // absorbed lazily: limbs stay below 2^31
     }
     permute(cbase);
-    if (wave == 0 && lane == 0) { if (lds_vload(C.flag + 3)) s = fr_zero<PF>(); stg(out + b, s); }   // a timed-out wait (never seen) must not pass for a digest
+    if (wave == 0 && lane < 16) C.sfin[cidx] = sr;                        // element 0, lazy
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fr29_t v; for (int i = 0; i < 9; ++i) v.l[i] = C.sfin[i];
+        fr_t s = chain_canon(v);
+        if (lds_vload(C.flag + 3)) s = fr_zero<PF>();                    // a timed-out wait (never seen) must not pass for a digest
+        stg(out + b, s);
+    }
 }
 #endif
 
