@@ -32,7 +32,6 @@ if what in ("leaf", "tree", "all"):
         p17 = ctx.poseidon_params_for_width(17)
         for _ in range(reps):
             ctx._chk(lib.stark_poseidon_hash_ds_batch_dev(ctx.h, p17.h, 16, 0, 0, 0, P(f), n, P(out)))
-ctx.sync(); ctx.close()
 
 if what in ("sponge", "all"):
     n = 1 << 14
@@ -40,3 +39,4 @@ if what in ("sponge", "all"):
     ctx._chk(lib.stark_synth_column_dev(ctx.h, 1, 2, 0, n, P(col)))
     for _ in range(reps):
         ctx._chk(lib.stark_tr_hash_fields_tagged_dev(ctx.h, None, b"ALI/A", P(col), n, 1, P(out)))
+ctx.sync(); ctx.close()
