@@ -155,7 +155,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     if (n == 0) return STARK_OK;
     TrJob J; J.prefix = frame; J.np = np; J.suffix = frame + np; J.ns = ns; J.cap = host::h_tag("FSv1-TRANSCRIPT-INIT"); J.k = k; J.n = n;
     if (!ctx->opt_poseidon_lane_only && !ctx->opt_sponge_one_wave && tp->dev.chain_a && n <= 1024 && k >= 128) {
-        // a few LONG sponges (a column digest of a sharded prove, a long Fiat-Shamir input): three waves per chain (poseidon_chain.hpp)
+        // a few LONG sponges (a column digest of a sharded prove, a long Fiat-Shamir input): five waves per chain (poseidon_chain.hpp)
         TrMultiJob M; M.cap = J.cap; M.batch = nullptr; M.stride = k;
         for (int c = 0; c < 4; ++c) { M.prefix[c] = frame; M.np[c] = np; M.suffix[c] = frame + np; M.ns[c] = ns; M.fields[c] = fields_dev; M.k[c] = k; }
         return launch_column_sponges(ctx, tp, M, (unsigned)n, out_dev);
@@ -171,7 +171,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
     STARK_HIP(ctx, hipGetLastError());
     return STARK_OK;
 }
-// Long serial sponges: three waves per chain (poseidon_chain.hpp) unless the option "sponge_one_wave" asks for the round-2 one-wave form.
+// Long serial sponges: five waves per chain (poseidon_chain.hpp) unless the option "sponge_one_wave" asks for the round-2 one-wave form.
 static int32_t launch_column_sponges(stark_ctx* ctx, stark_params* tp, const TrMultiJob& J, unsigned nblocks, fr_t* out_dev) {
     if (tp->dev.chain_a && !ctx->opt_sponge_one_wave) {
         const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i]; RK.dbg = (uint32_t)ctx->opt_sponge_debug;

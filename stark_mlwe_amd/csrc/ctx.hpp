@@ -80,7 +80,7 @@ struct stark_ctx {
     int opt_ntt_log_tile = 11;           // log2 of the elements of an NTT tile (8..12); -1 would mean "auto" (the default also shrinks for small launches)
     bool opt_ntt_log_tile_forced = false;
     int opt_ntt_min_waves = 2;           // occupancy hint of the NTT kernels (2 or 4 waves per SIMD)
-    int opt_sponge_debug = 0;            // timing experiments on the three-wave sponge (bit 0: A does not wait, 1: B idle, 2: C idle, 3: no full rounds, 4: no partial rounds); digests are WRONG when set
+    int opt_sponge_debug = 0;            // timing experiments on the five-wave sponge (bit 0: A does not wait, 1: B idle, 2: C idle, 3: no full rounds, 4: no partial rounds); digests are WRONG when set
     bool opt_sponge_one_wave = false;    // long serial sponges on ONE wave (poseidon_coop.hpp, round 2) instead of three (poseidon_chain.hpp) (diagnostic / comparison)
     bool opt_poseidon_lane_only = false; // one-lane-per-sponge kernels instead of the wave-pair / one-wave forms (diagnostic)
 

@@ -204,7 +204,7 @@ struct KernelConsts {
     std::vector<uint32_t> mds29, mds_pre29;   // dense forms for the one-wave kernel (every entry meets an S-box output: all scaled)
     // t = 17 only: the dense matrices as int8 MFMA operand fragments (signed radix-256 digits, Toeplitz windows), see mfma_frags
     std::vector<int8_t> mds_frag, mds_pre_frag;
-    // t = 17 only: the partial rounds UNROLLED over all rp rounds for the three-wave latency kernel (poseidon_chain.hpp):
+    // t = 17 only: the partial rounds UNROLLED over all rp rounds for the five-wave latency kernel (poseidon_chain.hpp):
     //     X_{q+1} = c_{q+1} + sum_j u_{q,j} s_j^(0) + a_q y_q + sum_{p<q} Gamma_{q,p} y_p,   y_q = X_q^5,   Gamma_{q,p} = sum_j u_{q,j} w_{p,j}
     // Every entry multiplies a y that reaches it through THREE Montgomery steps by 2^261 on operands carrying 2^256, so it is stored as
     // nine 29-bit limbs of c * 2^25 * 2^256 mod r (= c * (2^261)^5 / (2^256)^4): the product lands back in the 2^256 domain.
@@ -316,7 +316,7 @@ inline KernelConsts make_kernel_consts(const PoseidonConsts& c) {
     k.sparse29 = to_radix29(k.sparse, a_and_w); k.gamma29 = to_radix29(k.gamma, all);
     k.mds29 = to_radix29(k.mds, all); k.mds_pre29 = to_radix29(k.mds_pre, all);
     if (t == 17) { k.mds_frag = mfma_frags(k.mds, t); k.mds_pre_frag = mfma_frags(k.mds_pre, t); }      // the wave-pair kernels' full rounds (poseidon_pair.hpp)
-    if (t == 17 && c.rp == 64) {                                                                         // the three-wave latency kernel (poseidon_chain.hpp)
+    if (t == 17 && c.rp == 64) {                                                                         // the five-wave latency kernel (poseidon_chain.hpp)
         const int rp = c.rp, w = 2 * t - 1;
         const fr_t scale = fr_from_u64<PF>(1ull << 25);
         auto limbs = [&](const fr_t& v, uint32_t* out) { const fr29_t u = fr29_unpack(h_mul(v, scale)); for (int i = 0; i < 9; ++i) out[i] = u.l[i]; };

@@ -1,4 +1,4 @@
-// stark_mlwe_amd/csrc/poseidon_chain.hpp — the serial sponge as THREE cooperating waves (gfx950): the latency form of round 3.
+// stark_mlwe_amd/csrc/poseidon_chain.hpp — the serial sponge as FIVE cooperating waves (gfx950): the latency form of round 3.
 //
 // The column sponges of DeepAliRealBuilder::build_f0 (crates/deep_ali/src/fri.rs:548-557 via tr_hash_fields_tagged, fri.rs:28-35) are
 // n0/16 DEPENDENT t = 17 permutations per column; they are 99.7 % of an end-to-end prove.  One wave per sponge (poseidon_coop.hpp) spends
@@ -8,17 +8,19 @@
 // Here the partial rounds are UNROLLED over all 64 rounds (host_util.hpp chain tables):
 //     X_{q+1} = [ c_{q+1} + sum_j u_{q,j} s_j^(0) ]  +  a_q y_q  +  Gamma_{q,q-1} y_{q-1}  +  sum_{p <= q-2} Gamma_{q,p} y_p ,   y_q = X_q^5
 //                 E_q (wave C)                          wave A        wave A (previous round)   H_q - E_q (wave B)
-// so that only X -> X^2 -> (a X) X^2 X^2 is on the dependent chain, and that chain runs in ROW FORM on wave A (poseidon_row, below): one
+// so that only X -> X^2 -> (a X) X^2 X^2 is on the dependent chain, and that chain runs in ROW FORM on wave A (namespace row, below): one
 // product spread over the 16 lanes of a DPP row, limb c on lane c — 9 + 9 + 5 multiply-accumulates per lane-parallel product instead of 117
-// on one lane: 250 ns per dependent product (tools/chain_row.hip, profiles/r03_chain_row_product.jsonl).  Four rows = four products per
+// on one lane: 233 ns per dependent product (tools/chain_row.hip, profiles/r03_chain_row_product.jsonl).  Four rows = four products per
 // slot sharing one broadcast operand: row 0 the chain (X^2, X^3, X^5), row 1 a_q X -> a_q y_q, row 2 Gamma_{q+1,q} X -> Gamma_{q+1,q} y_q.
 //   wave B  lane q keeps H_q: every round it adds Gamma_{q,p} y_p for all q >= p + 2 at once (one one-lane product, 64 lanes) and publishes
 //           H_{p+2}; it has a full round of slack.
 //   wave C  first E_q for all q (16-term dot products, four at a time, far ahead of the chain), then the lanes of the state,
 //           s_j = s_j^(0) + sum_p w_{p,j} y_p (four rounds per product slot), finished one product after the chain ends.
-// The waves talk through LDS mailboxes and monotonic counters (no barrier inside the 64 rounds); the eight full rounds stay on wave A as in
-// poseidon_coop.hpp.  The same field values as the reference's dense rounds: the host model below (chain_partial_model) is checked against
-// permute_dense in tests/test_hostcheck.py, the kernel against the oracle on the GPU.
+// The waves talk through LDS mailboxes and monotonic counters (no barrier inside the 64 rounds).
+// The eight FULL rounds keep the state in row form on all five waves (element e on row e & 3 of wave e >> 2): the 17 S-boxes run at once as
+// row-form products whose broadcast operand is each row's own (ds_swizzle); the dense rows stay one-lane work on waves 0..2.
+// 75 us per permutation (142 us on one wave).  The same field values as the reference's dense rounds: the host model below
+// (chain_partial_model) is checked against permute_dense in tests/test_hostcheck.py, the kernel against the oracle on the GPU.
 #pragma once
 #include "fr.hpp"
 #include "fr29.hpp"
@@ -148,7 +150,7 @@ __device__ __forceinline__ uint32_t row1_to_row0(uint32_t v) { return (uint32_t)
 __device__ __forceinline__ uint32_t row2_to_row0(uint32_t v) { return (uint32_t)__builtin_amdgcn_permlane32_swap(v, v, false, false)[1]; }   // lanes 0..15 <- lanes 32..47
 }  // namespace row
 
-// ---- the three-wave sponge ------------------------------------------------------------------------------------------------------------------------
+// ---- the five-wave sponge ------------------------------------------------------------------------------------------------------------------------
 // LDS words behind the one-wave kernel's area (coop_lds_bytes): mailboxes of the partial rounds.  Rows of 16 words: a row-form value is written /
 // read by the 16 lanes of a DPP row as they are (lanes 9..15 carry zeros).
 struct ChainLds {
@@ -366,7 +368,7 @@ __device__ __forceinline__ void chain_partial_rounds(uint32_t& sr, const Poseido
     sr = valid ? C.sfin[e * 16 + cidx] : 0u;
 }
 
-// The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of three waves per chain.  Same job description as
+// The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of five waves per chain.  Same job description as
 // k_tr_hash_coop_multi (block b: column b, or with J.batch column b & 3 of trace b >> 2).
 __global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_chain(PoseidonDev P, TrMultiJob J, row::Consts RK, fr_t* __restrict__ out) {
     extern __shared__ uint4 lds[];

@@ -17,7 +17,7 @@ struct PoseidonDev {           // device pointers to kernel-form constants (see 
     const uint32_t* lu29; const uint32_t* lu_pre29; const uint32_t* row0_29; const uint32_t* sparse29; const uint32_t* gamma29;
     const uint32_t* mds29; const uint32_t* mds_pre29;   // dense M and B_1*M (one-wave kernel)
     const void* mds_frag; const void* mds_pre_frag;     // t = 17: the same two matrices as int8 MFMA fragments (host_util.hpp mfma_frags); nullptr otherwise
-    // t = 17: the partial rounds unrolled over all rp rounds for the three-wave latency kernel (host_util.hpp chain_*, poseidon_chain.hpp); nullptr otherwise
+    // t = 17: the partial rounds unrolled over all rp rounds for the five-wave latency kernel (host_util.hpp chain_*, poseidon_chain.hpp); nullptr otherwise
     const uint32_t* chain_a; const uint32_t* chain_g; const uint32_t* chain_w;
 };
 

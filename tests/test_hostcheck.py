@@ -51,7 +51,7 @@ def test_constants_and_kernel_form_permutation(oracle, hostcheck, kind, t, seed,
     assert (hostcheck.permute_kernel_form(h, states, t) == want).all()      # LU + sparse partial rounds == dense rounds, bit for bit
     if t == 17:
         # the partial rounds unrolled over all 64 rounds from the chain tables (E_q, Gamma_{q,p}, w_{p,j} with their 2^25 scaling): the algebra
-        # and the tables of the three-wave latency kernel (poseidon_chain.hpp) give the reference's permutation, bit for bit
+        # and the tables of the five-wave latency kernel (poseidon_chain.hpp) give the reference's permutation, bit for bit
         assert (hostcheck.permute_chain_model(h, states, t) == want).all()
     hostcheck.params_free(h)
 

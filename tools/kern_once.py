@@ -1,6 +1,6 @@
 """tools/kern_once.py — runs the hot kernels a fixed number of times each, nothing else of weight, for counter profiling
 (rocprofv3 --pmc ... -- python3 tools/kern_once.py):  k_ntt_strided x2 + k_ntt_last (2^23 coset NTT), k_leaf_pair2 (2^22 leaves),
-k_hash_ds2<17> (one arity-16 level over 2^22 digests), k_tr_hash_chain (one serial sponge over 2^14 fields: the three-wave kernel).
+k_hash_ds2<17> (one arity-16 level over 2^22 digests), k_tr_hash_chain (one serial sponge over 2^14 fields: the five-wave kernel).
 Usage: kern_once.py [ntt|leaf|tree|sponge|all] [reps]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""timing experiments on the three-wave sponge (option sponge_debug; digests are wrong in these modes) — where a permutation's time goes"""
+"""timing experiments on the five-wave sponge (option sponge_debug; digests are wrong in these modes) — where a permutation's time goes"""
 import ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch

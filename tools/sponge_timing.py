@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/sponge_timing.py — us per dependent permutation of the serial column sponge (build_f0, crates/deep_ali/src/fri.rs:548-557):
-three-wave kernel (poseidon_chain.hpp) against the round-2 one-wave kernel (option sponge_one_wave), same digests."""
+five-wave kernel (poseidon_chain.hpp) against the round-2 one-wave kernel (option sponge_one_wave), same digests."""
 import ctypes as C
 import json
 import os
@@ -32,8 +32,8 @@ for k in (12, 16):
         res[mode] = (dt, aux.copy(), f0.cpu().numpy().copy())
     same = bool((res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all())
     nperm = n0 // 16 + 2
-    out.append({"log_n0": k, "three_wave_us_per_permutation": res[0][0] * 1e6 / nperm, "one_wave_us_per_permutation": res[1][0] * 1e6 / nperm,
-                "build_f0_ms_three_wave": res[0][0] * 1e3, "build_f0_ms_one_wave": res[1][0] * 1e3, "same_digests_and_f0": same})
+    out.append({"log_n0": k, "five_wave_us_per_permutation": res[0][0] * 1e6 / nperm, "one_wave_us_per_permutation": res[1][0] * 1e6 / nperm,
+                "build_f0_ms_five_wave": res[0][0] * 1e3, "build_f0_ms_one_wave": res[1][0] * 1e3, "same_digests_and_f0": same})
     print(json.dumps(out[-1]), flush=True)
 ctx._chk(lib.stark_ctx_set_option(ctx.h, b"sponge_one_wave", 0))
 ctx.close()
