@@ -306,7 +306,12 @@ def main():
         out.update({
             "roofline": {"bound": "hbm", "kernel": f"Fr-NTT 2^{log_n + LOG_BLOWUP} coset forward (k_ntt_strided x2 + k_ntt_last)", "achieved": ntt_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ntt_gbps / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes": ntt_bytes, "avg_ms": ntt_ms,
-                         "lde_2^%d_to_2^%d_ms_per_column" % (log_n, log_n + LOG_BLOWUP): lde_ms},
+                         "lde_2^%d_to_2^%d_ms_per_column" % (log_n, log_n + LOG_BLOWUP): lde_ms,
+                         # what actually binds a 255-bit NTT on this chip: integer multiply-accumulate issue, not HBM (VALU busy 90 %, counters in
+                         # profiles/*_sq_counters.json).  Algorithmic MACs per element: (log2 n)/2 butterflies + 3 table products (coset pre-scale, two inter-pass
+                         # twiddles), each one carry-free 9x9 product + one Montgomery step by 2^261 = 81 + 36 v_mad_u64_u32.
+                         "valu": {"unit": "lane-MAC/s (v_mad_u64_u32)", "macs_per_element": ((log_n + LOG_BLOWUP) / 2 + 3) * 117, "achieved": ((log_n + LOG_BLOWUP) / 2 + 3) * 117 * N / (ntt_ms * 1e-3),
+                                  "peak": mac_rate.value, "frac": ((log_n + LOG_BLOWUP) / 2 + 3) * 117 * N / (ntt_ms * 1e-3) / mac_rate.value, "peak_source": "stark_diag_mac_rate, measured live on this device"}},
             "poseidon": {"kernel": "k_leaf_pair2 (t=17), 2^%d leaves" % (log_n + LOG_BLOWUP), "ms": leaf_ms, "leaves_per_s": leaves_per_s,
                          "reference_dense_fr_mults_per_s": FR_MULTS_T17 * leaves_per_s,
                          "roofline": {"bound": "int-valu", "unit": "lane-MAC/s (v_mad_u64_u32)", "peak": mac_rate.value, "peak_source": "stark_diag_mac_rate, measured live on this device",
