@@ -289,8 +289,10 @@ __device__ __forceinline__ void chain_partial_rounds(uint32_t& sr, const Poseido
             uint32_t x2[9]; row::bcast(x2, t1);
             const uint32_t t2 = row::mul(x2, rw == 0 ? x : t1, RK, cidx);                             // X^3 | a X^3 | Gamma X^3
             const uint32_t t3 = row::mul(x2, t2, RK, cidx);                                           // y_q | a_q y_q | Gamma_{q+1,q} y_q
-            if (rw == 0) C.y[q * 16 + cidx] = t3;
-            if (lane == 0) chain_post(C.flag, 0, base + q + 1);
+            // y_q, then its counter: two volatile LDS stores in program order — LDS executes a wave's requests in order, so no s_waitcnt stands between
+            // them (a release fence here would stall the chain for the store's round trip every round)
+            if (rw == 0) lds_vstore(C.y + q * 16 + cidx, t3);
+            if (lane == 0) lds_vstore(C.flag + 0, base + q + 1);
             const uint32_t need = base + q + 1;
             const bool early = (int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)fe) - need) >= 0 && (int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)fh) - need) >= 0;
             if (!early && !(RK.dbg & 1)) {
