@@ -312,6 +312,9 @@ int32_t stark_ntt_rows_coset_dev(stark_ctx_t* ctx, int32_t field_id, const uint6
  *            without Python (the reference's Rust process) drives a multi-GPU LDE with one call per column.  (dist.py's ShardedLde is the same
  *            composition in Python and stays the form the CPU gloo tests exercise.) */
 int32_t stark_lde_sharded_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* block, size_t log_n, size_t log_blowup, const uint64_t* shift4, uint64_t* out);
+/* Diagnostic: the same phases for `nranks` VIRTUAL ranks on this one GPU, every exchange done as device copies — what checks the index arithmetic of
+ * stark_lde_sharded_dev for W > 1 without a second GPU.  evals: the whole 2^log_n vector; out: the whole extended vector (= stark_lde_dev's). */
+int32_t stark_diag_lde_sharded_emulated_dev(stark_ctx_t* ctx, int32_t field_id, int32_t nranks, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* shift4, uint64_t* out);
 int32_t stark_ntt_columns_coset_dev(stark_ctx_t* ctx, int32_t field_id, uint64_t* slab, size_t log_rows, size_t ncols, size_t col0, size_t log_n, const uint64_t* shift4);
 int32_t stark_permute3_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t d0, size_t d1, size_t d2, int32_t p0, int32_t p1, int32_t p2);
 int32_t stark_interleave_dev(stark_ctx_t* ctx, const uint64_t* src, uint64_t* dst, size_t n, size_t stride, size_t offset);

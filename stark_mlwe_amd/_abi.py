@@ -121,6 +121,7 @@ SIGNATURES = {
     "stark_ntt_rows_dev": (i32, [vp, i32, vp, sz, sz, i32, vp]),
     "stark_ntt_rows_coset_dev": (i32, [vp, i32, vp, vp, sz, sz, sz, sz, vp]),
     "stark_lde_sharded_dev": (i32, [vp, i32, vp, sz, sz, vp, vp]),
+    "stark_diag_lde_sharded_emulated_dev": (i32, [vp, i32, i32, vp, sz, sz, vp, vp]),
     "stark_ntt_columns_coset_dev": (i32, [vp, i32, vp, sz, sz, sz, sz, vp]),
     "stark_permute3_dev": (i32, [vp, vp, vp, sz, sz, sz, i32, i32, i32]),
     "stark_interleave_dev": (i32, [vp, vp, vp, sz, sz, sz]),

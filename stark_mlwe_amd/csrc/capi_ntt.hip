@@ -282,41 +282,79 @@ static int32_t exchange(stark_ctx* ctx, int W, const fr_t* send, fr_t* recv, siz
     if (W == 1 && !ctx->comm) { STARK_HIP(ctx, hipMemcpyAsync(recv, send, elems_per_peer * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream)); return STARK_OK; }
     return stark_comm_all_to_all_dev(ctx, send, recv, elems_per_peer * sizeof(fr_t));
 }
+// One rank's buffers and the five local phases between the four exchanges.  The same code runs under the real communicator (lde_sharded_run) and under
+// the in-process emulation of W ranks on one GPU (stark_diag_lde_sharded_emulated_dev: what checks the W > 1 index arithmetic without a second GPU).
+struct ShardPlan { int W, log_n, lb, log_rows, log_cols; uint64_t R, Cc, b, nrl, ncl, nl; };
+struct ShardRank { int rank; const fr_t* block; fr_t* out; DevBuf t0, t1, big0, big1; };
+static int32_t shard_plan(stark_ctx* ctx, int W, int log_n, int lb, ShardPlan& P) {
+    if (log_n < 2 || log_n + lb > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "lde_sharded: sizes");
+    P.W = W; P.log_n = log_n; P.lb = lb; P.log_rows = std::min(10, log_n / 2); P.log_cols = log_n - P.log_rows;
+    P.R = 1ull << P.log_rows; P.Cc = 1ull << P.log_cols; P.b = 1ull << lb;
+    if (W < 1 || (W & (W - 1)) || P.R % W || P.Cc % W) return ctx->fail(STARK_ERR_INVALID_ARG, "lde_sharded: the ranks must divide the 2^log_rows x 2^log_cols view");
+    P.nrl = P.R / W; P.ncl = P.Cc / W; P.nl = P.nrl * P.Cc;               // local rows, local columns, local elements of one size-n vector
+    return STARK_OK;
+}
+static int32_t shard_alloc(stark_ctx* ctx, const ShardPlan& P, ShardRank& K) {
+    STARK_HIP(ctx, K.t0.alloc(ctx, P.nl * sizeof(fr_t))); STARK_HIP(ctx, K.t1.alloc(ctx, P.nl * sizeof(fr_t)));
+    STARK_HIP(ctx, K.big0.alloc(ctx, P.b * P.nl * sizeof(fr_t))); STARK_HIP(ctx, K.big1.alloc(ctx, P.b * P.nl * sizeof(fr_t)));
+    return STARK_OK;
+}
+// phase k runs after exchange k (phase 0: before the first).  Exchange k sends `send_of(k)` and receives into `recv_of(k)`, `per_peer(k)` elements per peer.
+static const fr_t* shard_send(const ShardRank& K, int x) { return x == 0 ? K.t0.fr() : x == 1 ? K.t1.fr() : K.big1.fr(); }
+static fr_t* shard_recv(const ShardRank& K, int x) { return x == 0 ? K.t1.fr() : x == 1 ? K.t0.fr() : K.big0.fr(); }
+static uint64_t shard_per_peer(const ShardPlan& P, int x) { return x < 2 ? P.nrl * P.ncl : P.b * P.nrl * P.ncl; }
+template <class F>
+static int32_t shard_phase(stark_ctx* ctx, const ShardPlan& P, ShardRank& K, int phase, const fr_t& shift) {
+    const uint64_t W = P.W, nrl = P.nrl, ncl = P.ncl, nl = P.nl, b = P.b, R = P.R;
+    switch (phase) {
+    case 0:   // natural row block [nrl][W][ncl] -> [W][nrl][ncl]; exchange 0 makes it the column block [R][ncl]
+        return pack3(ctx, K.block, K.t0.fr(), nrl, W, ncl, 1, 0, 2);
+    case 1:   // inverse six-step transform: column phase + twiddle; exchange 1 is its transpose
+        return columns_run<F>(ctx, K.t1.fr(), P.log_rows, ncl, (uint64_t)K.rank * ncl, P.log_n, true);
+    case 2: { // [W][nrl][ncl] -> [nrl][C] (rows k1 of c[k1 + R k']); row phase with n^-1; first phase of every coset transform on that slab; pack for exchange 2
+        STARK_TRY(pack3(ctx, K.t0.fr(), K.t1.fr(), W, nrl, ncl, 1, 0, 2));
+        { DevBuf sc; const fr_t ninv = x32<F>(fr_inv<F>(fr_from_u64<F>(1ull << P.log_n)));
+          STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &ninv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+          STARK_TRY((ntt_run<F>(ctx, K.t1.fr(), P.log_cols, nrl, true, nullptr, sc.fr())));
+          STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }                                       // the scale word is freed on leaving this scope
+        const fr_t wN = fr_root_of_unity<F>((unsigned)(P.log_n + P.lb)); fr_t sh = shift;
+        for (uint64_t s_ = 0; s_ < b; ++s_) { STARK_TRY((rows_coset_run<F>(ctx, K.t1.fr(), K.big0.fr() + s_ * nl, nrl, P.log_cols, (uint64_t)K.rank * nrl, P.log_n, sh))); sh = fr_mul<F>(sh, wN); }
+        return pack3(ctx, K.big0.fr(), K.big1.fr(), b * nrl, W, ncl, 1, 0, 2); }                     // [b nrl][W][ncl] -> [W][b nrl][ncl]
+    case 3:   // [W][b][nrl ncl] -> [b][R][ncl] -> [b ncl][R]; size-R transforms; [b][ncl][R] -> [R][ncl][b] for exchange 3
+        STARK_TRY(pack3(ctx, K.big0.fr(), K.big1.fr(), W, b, nrl * ncl, 1, 0, 2));
+        STARK_TRY(pack3(ctx, K.big1.fr(), K.big0.fr(), b, R, ncl, 0, 2, 1));
+        STARK_TRY((ntt_run<F>(ctx, K.big0.fr(), P.log_rows, b * ncl, false, nullptr, nullptr)));
+        return pack3(ctx, K.big0.fr(), K.big1.fr(), b, ncl, R, 2, 1, 0);
+    default:  // [W][nrl][ncl b] -> [nrl][W][ncl b]: natural order of the interleaved result out[(K2 C + K1) b + s]
+        return pack3(ctx, K.big0.fr(), K.out, W, nrl, ncl * b, 1, 0, 2);
+    }
+}
 template <class F>
 static int32_t lde_sharded_run(stark_ctx* ctx, const fr_t* block, int log_n, int lb, const fr_t& shift, fr_t* out) {
     const int W = ctx->comm ? stark_comm_size(ctx) : 1, rank = ctx->comm ? stark_comm_rank(ctx) : 0;
-    if (log_n < 2 || log_n + lb > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "lde_sharded: sizes");
-    const int log_rows = std::min(10, log_n / 2), log_cols = log_n - log_rows;
-    const uint64_t R = 1ull << log_rows, Cc = 1ull << log_cols, b = 1ull << lb;
-    if (W < 1 || (W & (W - 1)) || R % W || Cc % W) return ctx->fail(STARK_ERR_INVALID_ARG, "lde_sharded: the ranks must divide the 2^log_rows x 2^log_cols view");
-    const uint64_t nrl = R / W, ncl = Cc / W, nl = nrl * Cc;               // local rows, local columns, local elements of one size-n vector
-    DevBuf t0, t1, big0, big1;
-    STARK_HIP(ctx, t0.alloc(ctx, nl * sizeof(fr_t))); STARK_HIP(ctx, t1.alloc(ctx, nl * sizeof(fr_t)));
-    STARK_HIP(ctx, big0.alloc(ctx, b * nl * sizeof(fr_t))); STARK_HIP(ctx, big1.alloc(ctx, b * nl * sizeof(fr_t)));
-    // 1. natural row block [nrl][W][ncl] -> [W][nrl][ncl]; exchange -> the column block [R][ncl]
-    STARK_TRY(pack3(ctx, block, t0.fr(), nrl, W, ncl, 1, 0, 2));
-    STARK_TRY(exchange(ctx, W, t0.fr(), t1.fr(), nrl * ncl));
-    // 2. inverse six-step transform: column phase + twiddle, its transpose, row phase with n^-1
-    STARK_TRY((columns_run<F>(ctx, t1.fr(), log_rows, ncl, (uint64_t)rank * ncl, log_n, true)));
-    STARK_TRY(exchange(ctx, W, t1.fr(), t0.fr(), nrl * ncl));
-    STARK_TRY(pack3(ctx, t0.fr(), t1.fr(), W, nrl, ncl, 1, 0, 2));                                   // [nrl][C]: rows k1 of c[k1 + R k']
-    { DevBuf sc; const fr_t ninv = x32<F>(fr_inv<F>(fr_from_u64<F>(1ull << log_n)));
-      STARK_HIP(ctx, sc.alloc(ctx, sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(sc.p, &ninv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
-      STARK_TRY((ntt_run<F>(ctx, t1.fr(), log_cols, nrl, true, nullptr, sc.fr())));
-      STARK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }                                           // the scale word is freed on leaving this scope
-    // 3. first phase of every coset transform on that same slab (nothing is exchanged between the inverse and the forward transforms)
-    const fr_t wN = fr_root_of_unity<F>((unsigned)(log_n + lb)); fr_t sh = shift;
-    for (uint64_t s_ = 0; s_ < b; ++s_) { STARK_TRY((rows_coset_run<F>(ctx, t1.fr(), big0.fr() + s_ * nl, nrl, log_cols, (uint64_t)rank * nrl, log_n, sh))); sh = fr_mul<F>(sh, wN); }
-    // 4. ONE exchange for all cosets: [b nrl][W][ncl] -> [W][b nrl][ncl]; then [W][b][nrl ncl] -> [b][R][ncl] -> [b ncl][R]; size-R transforms
-    STARK_TRY(pack3(ctx, big0.fr(), big1.fr(), b * nrl, W, ncl, 1, 0, 2));
-    STARK_TRY(exchange(ctx, W, big1.fr(), big0.fr(), b * nrl * ncl));
-    STARK_TRY(pack3(ctx, big0.fr(), big1.fr(), W, b, nrl * ncl, 1, 0, 2));
-    STARK_TRY(pack3(ctx, big1.fr(), big0.fr(), b, R, ncl, 0, 2, 1));
-    STARK_TRY((ntt_run<F>(ctx, big0.fr(), log_rows, b * ncl, false, nullptr, nullptr)));
-    // 5. ONE exchange to natural blocks of the interleaved result out[(K2 C + K1) b + s]: [b][ncl][R] -> [R][ncl][b]; exchange; [W][nrl][ncl b] -> [nrl][W][ncl b]
-    STARK_TRY(pack3(ctx, big0.fr(), big1.fr(), b, ncl, R, 2, 1, 0));
-    STARK_TRY(exchange(ctx, W, big1.fr(), big0.fr(), nrl * ncl * b));
-    STARK_TRY(pack3(ctx, big0.fr(), out, W, nrl, ncl * b, 1, 0, 2));
+    ShardPlan P; STARK_TRY(shard_plan(ctx, W, log_n, lb, P));
+    ShardRank K; K.rank = rank; K.block = block; K.out = out; STARK_TRY(shard_alloc(ctx, P, K));
+    for (int phase = 0; phase < 5; ++phase) {
+        STARK_TRY((shard_phase<F>(ctx, P, K, phase, shift)));
+        if (phase < 4) STARK_TRY(exchange(ctx, W, shard_send(K, phase), shard_recv(K, phase), shard_per_peer(P, phase)));
+    }
+    return STARK_OK;
+}
+// W virtual ranks on ONE GPU: the phases of every rank in turn, each exchange as device copies (chunk q of rank p's send buffer -> chunk p of rank q's
+// receive buffer).  Exactly the code and index arithmetic of the real W-rank run, minus RCCL.
+template <class F>
+static int32_t lde_sharded_emulated(stark_ctx* ctx, int W, const fr_t* evals, int log_n, int lb, const fr_t& shift, fr_t* out) {
+    ShardPlan P; STARK_TRY(shard_plan(ctx, W, log_n, lb, P));
+    std::vector<ShardRank> K(W);
+    for (int r = 0; r < W; ++r) { K[r].rank = r; K[r].block = evals + (size_t)r * P.nl; K[r].out = out + ((size_t)r * P.nl << lb); STARK_TRY(shard_alloc(ctx, P, K[r])); }
+    for (int phase = 0; phase < 5; ++phase) {
+        for (int r = 0; r < W; ++r) STARK_TRY((shard_phase<F>(ctx, P, K[r], phase, shift)));
+        if (phase < 4) {
+            const uint64_t per = shard_per_peer(P, phase);
+            for (int p = 0; p < W; ++p) for (int q = 0; q < W; ++q)
+                STARK_HIP(ctx, hipMemcpyAsync(shard_recv(K[q], phase) + (size_t)p * per, shard_send(K[p], phase) + (size_t)q * per, per * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
     return STARK_OK;
 }
 
@@ -328,6 +366,14 @@ int32_t stark_lde_sharded_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t
     const fr_t sh = load_fr(shift4);
     if (field_id == STARK_FIELD_PALLAS_FR) return lde_sharded_run<PallasFr>(ctx, as_fr(block), (int)log_n, (int)log_blowup, sh, as_fr(out));
     if (field_id == STARK_FIELD_BLS12_381_FR) return lde_sharded_run<Bls12381Fr>(ctx, as_fr(block), (int)log_n, (int)log_blowup, sh, as_fr(out));
+    return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
+}
+int32_t stark_diag_lde_sharded_emulated_dev(stark_ctx_t* ctx, int32_t field_id, int32_t nranks, const uint64_t* evals, size_t log_n, size_t log_blowup, const uint64_t* shift4, uint64_t* out) {
+    if (!ctx || !evals || !out || !shift4 || evals == out || nranks < 1) return STARK_ERR_INVALID_ARG;
+    STARK_TRY(ctx_enter(ctx));
+    const fr_t sh = load_fr(shift4);
+    if (field_id == STARK_FIELD_PALLAS_FR) return lde_sharded_emulated<PallasFr>(ctx, nranks, as_fr(evals), (int)log_n, (int)log_blowup, sh, as_fr(out));
+    if (field_id == STARK_FIELD_BLS12_381_FR) return lde_sharded_emulated<Bls12381Fr>(ctx, nranks, as_fr(evals), (int)log_n, (int)log_blowup, sh, as_fr(out));
     return ctx->fail(STARK_ERR_INVALID_ARG, "unknown field id");
 }
 int32_t stark_ntt_rows_coset_dev(stark_ctx_t* ctx, int32_t field_id, const uint64_t* src, uint64_t* dst, size_t nrows, size_t log_cols, size_t row0, size_t log_n, const uint64_t* shift4) {

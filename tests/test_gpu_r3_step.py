@@ -206,3 +206,21 @@ def test_library_sharded_lde_one_rank_equals_single_gpu_lde(gpu_ctx, oracle, fie
     assert bool((a == b).all())
     if log_n <= 13:
         assert (a.cpu().numpy().view(np.uint64) == oracle.lde(field, host, lb, shift)).all()
+
+
+@pytest.mark.parametrize("W,log_n,lb", [(2, 6, 2), (2, 12, 3), (4, 12, 3), (8, 14, 3), (4, 21, 2), (8, 20, 3)])
+def test_library_sharded_lde_emulated_ranks_equal_single_gpu_lde(gpu_ctx, W, log_n, lb):
+    """The index arithmetic of stark_lde_sharded_dev for W > 1 (packs, per-peer chunks, global row / column offsets, the coset interleave) checked on one
+    GPU: stark_diag_lde_sharded_emulated_dev runs the SAME phase code for W virtual ranks and does every exchange as device copies; the concatenated
+    rank outputs must equal stark_lde_dev of the whole column.  (RCCL itself moves opaque bytes; what it cannot be tested for here is hardware.)"""
+    import torch
+    from stark_mlwe_amd.api import _ptr
+    import bench
+    n = 1 << log_n
+    x = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx._chk(gpu_ctx.lib.stark_synth_column_dev(gpu_ctx.h, 901 + log_n + W, 2, 0, n, C.c_void_p(x.data_ptr())))
+    shift = bench._mont_small(5)
+    a = torch.empty((n << lb, 4), dtype=torch.int64, device="cuda"); b = torch.empty_like(a)
+    gpu_ctx._chk(gpu_ctx.lib.stark_diag_lde_sharded_emulated_dev(gpu_ctx.h, 0, W, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(a.data_ptr())))
+    gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, 0, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(b.data_ptr())))
+    assert bool((a == b).all())
