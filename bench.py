@@ -386,15 +386,17 @@ def reference_bench(ctx, np, csv_path, gpus):
 
 # The reference bench's other schedules (channel/benches/end_to_end.rs:195-201) and the Criterion means its authors left under
 # target/criterion/e2e_mf_fri/{prove,verify}-<label>/<k>/new/estimates.json (Apple arm64, one thread), ms.
-PRESETS = [("mod16", [16, 16, 16, 16]), ("uni32x3", [32, 32, 32]), ("uni64x2x8", [64, 64, 8]), ("hi64_32_8", [64, 32, 8]), ("hi32_32_16", [32, 32, 16])]
+PRESETS = [("mod16", [16, 16, 16, 16]), ("uni32x3", [32, 32, 32]), ("uni64x2x8", [64, 64, 8]), ("hi64_32_8", [64, 32, 8]), ("hi32_32_16", [32, 32, 16]),
+           # the 128-fold schedules (end_to_end.rs:202-210; layers of arity 128 = Poseidon width 129): no published timings, measured at k = 16
+           ("uni128", [128]), ("uni128x2", [128, 128]), ("hi128_64", [128, 64]), ("hi128_32", [128, 32]), ("hi128_16", [128, 16]), ("hi128_64_8", [128, 64, 8]), ("hi128_32_8", [128, 32, 8])]
 PUBLISHED_PRESET_MS = {("mod16", 16): (55906.8, 240.5), ("uni32x3", 15): (27146.9, 162.1), ("uni32x3", 16): (54165.2, 195.1), ("uni64x2x8", 15): (26999.7, 135.5),
                        ("uni64x2x8", 16): (53552.6, 166.4), ("hi64_32_8", 14): (13454.9, 130.8), ("hi64_32_8", 15): (27069.2, 150.0), ("hi64_32_8", 16): (53520.7, 183.3),
                        ("hi32_32_16", 14): (13647.6, 148.4), ("hi32_32_16", 15): (27093.2, 169.0), ("hi32_32_16", 16): (54904.8, 196.2)}
 
 
 def preset_bench(ctx, np, torch, dev, csv_path, gpus):
-    """deep_fri_prove / deep_fri_verify for the reference bench's presets other than "paper" at the sizes its authors measured (k_min .. 16):
-    layers of arity 32 / 64 (Poseidon widths t = 33 / 65).  Inputs: the synthetic trace (seed 0x5EED0000 + k) — the reference's seed chain for
+    """deep_fri_prove / deep_fri_verify for the reference bench's presets other than "paper" at the sizes its authors measured (k_min .. 16; the 128-fold
+    schedules, for which they left no timings, at k = 16): layers of arity 32 / 64 / 128 (Poseidon widths t = 33 / 65 / 129, one wave per node).  Inputs: the synthetic trace (seed 0x5EED0000 + k) — the reference's seed chain for
     these presets depends on how many ks its "paper" loop ran, which the repo does not record, and it published no proof sizes for them.
     Per row: end-to-end prove from (a, s, e, t), the stages after build_f0 alone (`prove_given_f0_ms`), verify."""
     from stark_mlwe_amd.api import _ptr
@@ -403,7 +405,7 @@ def preset_bench(ctx, np, torch, dev, csv_path, gpus):
     for label, sched_l in PRESETS:
         sch = np.ascontiguousarray(sched_l, dtype=np.uint64)
         kmin = sum(int(m).bit_length() - 1 for m in sched_l)
-        for k in range(max(14, kmin), 17):
+        for k in range(max(14, kmin) if 128 not in sched_l else 16, 17):
             nk = 1 << k
             cs = [torch.empty((nk, 4), dtype=torch.int64, device=dev) for _ in range(4)]
             for c in range(4):
