@@ -274,6 +274,8 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
 }  // extern "C"
 // everything the context owns; runs when the context has been destroyed AND its last handle is gone
 static void ctx_teardown(stark_ctx* ctx) {
+    for (stark_ctx* a : ctx->aux) if (a) ctx_teardown(a);            // worker contexts hand out no handles of their own
+    ctx->aux.clear();
     (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
     stark::comm_destroy(ctx);
     stark::ntt_plans_free(ctx);
@@ -313,11 +315,27 @@ int32_t stark_ctx_trim(stark_ctx_t* ctx) {
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& kv : ctx->pool_free) { for (void* q : kv.second) (void)hipFree(q); kv.second.clear(); }
     ctx->pool_cached_bytes = 0;
+    for (stark_ctx* a : ctx->aux) if (a) (void)stark_ctx_trim(a);
     stark::ntt_plans_free(ctx);                  // NTT plans with their direct twiddle / coset tables (up to 3*n*32 B per plan) are rebuilt on demand
     if (ctx->scratch) { (void)hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
     return STARK_OK;
 }
 size_t stark_ctx_cached_bytes(stark_ctx_t* ctx) { return ctx ? ctx->pool_cached_bytes : 0; }
+}  // extern "C"
+namespace stark {
+int32_t ctx_aux(stark_ctx* ctx, size_t k, stark_ctx** out) {
+    while (ctx->aux.size() <= k) {
+        stark_ctx* a = nullptr; int32_t rc = stark_ctx_create(ctx->device, STARK_STREAM_PRIVATE, &a);
+        if (rc) return ctx->fail(rc, "worker context");
+        ctx->aux.push_back(a);
+    }
+    stark_ctx* a = ctx->aux[k];
+    a->opt_ntt_direct_max_log = ctx->opt_ntt_direct_max_log; a->opt_ntt_log_tile = ctx->opt_ntt_log_tile; a->opt_ntt_log_tile_forced = ctx->opt_ntt_log_tile_forced;
+    a->opt_ntt_min_waves = ctx->opt_ntt_min_waves; a->opt_poseidon_lane_only = ctx->opt_poseidon_lane_only; a->opt_sponge_one_wave = ctx->opt_sponge_one_wave;
+    *out = a; return STARK_OK;
+}
+}
+extern "C" {
 int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return STARK_ERR_INVALID_ARG;
     STARK_TRY(ctx_enter(ctx));

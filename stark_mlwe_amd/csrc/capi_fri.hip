@@ -3,6 +3,7 @@
 // crates/deep_ali/src/fri.rs and crates/deep_ali/src/lib.rs).  C-ABI in include/stark_mlwe.h.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <map>
 #include "ctx.hpp"
@@ -374,23 +375,41 @@ static int32_t prove_batch_impl(stark_ctx* ctx, size_t B, const uint64_t* const*
     std::vector<fr_t> fu(B);
     STARK_HIP(ctx, hipMemcpyAsync(fu.data(), fused.p, B * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream)); STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     auto t1 = now();
-    // (3) per trace: merge, commit phase, query phase
+    // (3) per trace: merge, commit phase, query phase.  These tails are latency-bound (a few ms of small dependent launches each), so up to four of them run
+    // side by side: worker contexts of this context (same device, private streams, own pools), one host thread each, traces dealt round-robin.  The inputs
+    // are resident and this context's stream is idle (synchronised above), so the workers' streams may read them.
     const fr_t omega = fr_root_of_unity<PallasFr>((unsigned)ilog2(n0));
-    DevBuf f0buf; if (f0buf.alloc(ctx, n0 * sizeof(fr_t)) != hipSuccess) return ctx->fail(STARK_ERR_OOM, "f0");
-    auto bail = [&](int32_t rc) { for (size_t p = 0; p < B; ++p) if (out[p]) { delete out[p]; out[p] = nullptr; } return rc; };
-    for (size_t p = 0; p < B; ++p) {
-        auto u0 = now();
-        fr_t z, beta; ali_z_beta_from_fused(fu[p], n0, seed_f[p], &z, &beta);
-        { int32_t rc = ali_merge_dev_impl(ctx, as_fr(a[p]), as_fr(s[p]), as_fr(e[p]), as_fr(t[p]), nullptr, host::h_zero(), omega, z, n0, f0buf.fr(), nullptr); if (rc) return bail(rc); }
-        auto u1 = now();
-        stark_fri_state* S = nullptr; { int32_t rc = fri_build_impl(ctx, f0buf.fr(), n0, schedule, L, seed_z, &S); if (rc) return bail(rc); }
-        auto u2 = now();
-        stark_proof* P = new stark_proof();
-        { int32_t rc = prove_queries_encode(ctx, S, n0, r, P); delete S; if (rc) { delete P; return bail(rc); } }
-        auto u3 = now();
-        P->ms[0] = ms_of(t0, t1) + ms_of(u0, u1);      // the shared sponge stage (whole batch) + this trace's merge
-        P->ms[1] = ms_of(u1, u2); P->ms[2] = ms_of(u2, u3);
-        out[p] = P;
+    const double shared_ms = ms_of(t0, t1);
+    const size_t NT = std::min<size_t>(B, 4);
+    std::vector<stark_ctx*> cx(NT); for (size_t w = 0; w < NT; ++w) STARK_TRY(ctx_aux(ctx, w, &cx[w]));
+    std::vector<int32_t> rcs(NT, STARK_OK);
+    auto worker = [&](size_t w) {
+        stark_ctx* c = cx[w];
+        int32_t rc = ctx_enter(c); if (rc) { rcs[w] = rc; return; }
+        DevBuf f0buf; if (f0buf.alloc(c, n0 * sizeof(fr_t)) != hipSuccess) { rcs[w] = c->fail(STARK_ERR_OOM, "f0"); return; }
+        for (size_t p = w; p < B; p += NT) {
+            auto u0 = now();
+            fr_t z, beta; ali_z_beta_from_fused(fu[p], n0, seed_f[p], &z, &beta);
+            rc = ali_merge_dev_impl(c, as_fr(a[p]), as_fr(s[p]), as_fr(e[p]), as_fr(t[p]), nullptr, host::h_zero(), omega, z, n0, f0buf.fr(), nullptr); if (rc) { rcs[w] = rc; return; }
+            auto u1 = now();
+            stark_fri_state* S = nullptr; rc = fri_build_impl(c, f0buf.fr(), n0, schedule, L, seed_z, &S); if (rc) { rcs[w] = rc; return; }
+            auto u2 = now();
+            stark_proof* P = new stark_proof();
+            rc = prove_queries_encode(c, S, n0, r, P); delete S; if (rc) { delete P; rcs[w] = rc; return; }
+            auto u3 = now();
+            P->ms[0] = shared_ms + ms_of(u0, u1);          // the shared sponge stage (whole batch) + this trace's merge
+            P->ms[1] = ms_of(u1, u2); P->ms[2] = ms_of(u2, u3);
+            out[p] = P;
+        }
+        (void)hipStreamSynchronize(c->stream);
+    };
+    if (NT == 1) worker(0);
+    else { std::vector<std::thread> th; for (size_t w = 0; w < NT; ++w) th.emplace_back(worker, w); for (auto& x : th) x.join(); }
+    STARK_TRY(ctx_enter(ctx));
+    for (size_t w = 0; w < NT; ++w) if (rcs[w]) {
+        ctx->err = cx[w]->err;
+        for (size_t p = 0; p < B; ++p) if (out[p]) { delete out[p]; out[p] = nullptr; }
+        return rcs[w];
     }
     return STARK_OK;
 }

@@ -49,6 +49,7 @@ struct stark_ctx {
     hipStream_t side_stream = nullptr;               // lazily created: small independent jobs that run underneath a big one (fri_build)
     std::string err;
     int live_handles = 0; bool destroy_pending = false;   // see CtxRef
+    std::vector<stark_ctx*> aux;                     // worker contexts on the same device (private streams) for the tails of a batch prove; created lazily, torn down with this context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;         // stark_timer_start / stop
     hipEvent_t ev_fork = nullptr;                    // orders the side stream after the main one
     // lazily created constants
@@ -134,6 +135,7 @@ int32_t ctx_merkle_params(stark_ctx* ctx, int t, stark_params** out);
 int32_t ctx_scratch(stark_ctx* ctx, size_t bytes, void** out);
 int32_t ctx_side_stream(stark_ctx* ctx, hipStream_t* out);
 int32_t ctx_enter(stark_ctx* ctx);                                   // makes the context's device current (every entry point)
+int32_t ctx_aux(stark_ctx* ctx, size_t k, stark_ctx** out);          // the k-th worker context of `ctx` (same device, private stream, the parent's options)
 void comm_destroy(stark_ctx* ctx);
 void ntt_set_attrs();                                                // per-device kernel attributes of the NTT kernels (capi_ntt.hip)
 void ntt_plans_free(stark_ctx* ctx);

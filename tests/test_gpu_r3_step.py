@@ -69,9 +69,8 @@ def test_batch_prove_equals_single_proves(gpu_ctx, oracle, k, B):
     """stark_deep_fri_prove_batch_dev: B independent traces in one call (the reference's bench proves one after another,
     channel/benches/end_to_end.rs:229-309).  Each proof is byte-equal to the single prove of its trace (and, at 2^10, to the
     oracle's).  The 4 * B serial column sponges of crates/deep_ali/src/fri.rs:548-557 run concurrently, so the sponge stage of the batch costs what it
-    costs for one trace; the B tails (merge, commit, queries: about 7 ms each at 2^16, latency-bound) still run one after another.  With the round-2
-    sponge (0.59 s per prove) 16 proves took 1.26 x one; the five-wave sponge brought ONE prove to 0.31 s and the batch to 0.42 s — 1.35 x.  The bound
-    below is on what the batch is for: 16 proves in less than the time of two."""
+    costs for one trace; the B tails (merge, commit, queries: a few ms each, latency-bound) run up to four at a time on worker contexts.  16 proves of
+    2^16 rows: 0.39 s against 0.31 s for one."""
     import time
     import torch
     from stark_mlwe_amd.api import DeepFriParams
@@ -107,7 +106,7 @@ def test_batch_prove_equals_single_proves(gpu_ctx, oracle, k, B):
         rec = {"log_n0": k, "batch": B, "one_prove_s": t_one, "batch_s": t_batch, "ratio": t_batch / t_one}
         out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
         json.dump(rec, open(os.path.join(out, "batch_prove.json"), "w"), indent=1)
-        assert t_batch <= 1.6 * t_one and t_batch <= 0.55, rec
+        assert t_batch <= 1.4 * t_one, rec
 
 
 PRESET_CASES = [("mod16", [16, 16, 16, 16], 16), ("uni32x3", [32, 32, 32], 15), ("uni64x2x8", [64, 64, 8], 15), ("hi64_32_8", [64, 32, 8], 14), ("hi32_32_16", [32, 32, 16], 14)]
