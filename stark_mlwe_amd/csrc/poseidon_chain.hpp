@@ -275,10 +275,11 @@ __device__ __forceinline__ void chain_partial_rounds(uint32_t& sr, const Poseido
         // ---- A: the chain, row form ------------------------------------------------------------------------------------------------------------
         const uint32_t rw = lane >> 4;
         uint32_t x = rw == 0 ? row::norm(s_norm + C.rcp0[cidx], cidx) : 0u;                           // X_0 = s_0 + c_0: element 0 lives on this wave's row 0
-        uint32_t prev = 0;
+        uint32_t prev = 0, kc_next = C.ca[lane];
 #pragma unroll 1
         for (int q = 0; q < RP; ++q) {
-            const uint32_t kc = C.ca[q * 64 + lane];
+            const uint32_t kc = kc_next;                                                               // this round's row constants were fetched a round ago
+            kc_next = C.ca[((q + 1) & (RP - 1)) * 64 + lane];
             // E_q and H_q - E_q were posted long before this round ends (wave C runs far ahead, wave B had a full round): read the counters and the two
             // rows NOW, underneath the products, and fall back to waiting only if a counter was not there yet.  (Counter first, data after: LDS serves a
             // wave's requests in order, and the accesses are volatile, so a counter that reads "posted" vouches for the data read behind it.)
