@@ -199,6 +199,14 @@ int hc_permute_chain_model(void* h, uint64_t* states, size_t n) {
     }
     return 0;
 }
+// the constants of the row-form Montgomery step (poseidon_chain.hpp row_consts_host): nine limbs of -r^-1 mod 2^261, five limbs of t = r - 2^254
+int hc_row_consts(uint32_t* out14) { const RowConstsHost K = row_consts_host(); for (int i = 0; i < 9; ++i) out14[i] = K.ni[i]; for (int i = 0; i < 5; ++i) out14[9 + i] = K.t[i]; return 0; }
+// the chain tables' shapes: chain_a [rp][64], chain_g [rp][9][64], chain_w [rp][t-1][9]; copies one table out (which = 0, 1, 2); returns its length in words
+size_t hc_chain_table(void* h, int which, uint32_t* out, size_t cap) {
+    HcParams* P = (HcParams*)h; const std::vector<uint32_t>& v = which == 0 ? P->kc.chain_a : which == 1 ? P->kc.chain_g : P->kc.chain_w;
+    if (out) for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return v.size();
+}
 // reference-form (dense) permutation on the host, from the same constants
 int hc_permute_dense(void* h, uint64_t* states, size_t n) {
     HcParams* P = (HcParams*)h; int t = P->ref.t; std::vector<fr_t> st(t);

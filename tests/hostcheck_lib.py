@@ -73,6 +73,14 @@ class HostCheck:
         s = A(states).copy(); rc = self.l.hc_full_round_linear(h, which, 1 if pre else 0, P(s), C.c_size_t(s.size // (17 * 4)))
         assert rc == 0, rc; return s
 
+    def row_consts(self):
+        out = np.zeros(14, np.uint32); self.l.hc_row_consts(out.ctypes.data_as(C.c_void_p)); return out
+
+    def chain_table(self, h, which):
+        self.l.hc_chain_table.restype = C.c_size_t
+        n = self.l.hc_chain_table(h, which, None, C.c_size_t(0)); out = np.zeros(n, np.uint32)
+        self.l.hc_chain_table(h, which, out.ctypes.data_as(C.c_void_p), C.c_size_t(n)); return out
+
     def permute_chain_model(self, h, states, t=17):
         s = A(states).copy(); rc = self.l.hc_permute_chain_model(h, P(s), C.c_size_t(s.size // (4 * t))); assert rc == 0, rc; return s
 

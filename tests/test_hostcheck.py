@@ -208,3 +208,25 @@ def test_matrix_core_full_round_tables_and_fold(oracle, hostcheck):
             assert (a == b).all(), (kind, pre)
             assert not (a == st).all()
         hostcheck.params_free(h)
+
+
+def test_row_form_montgomery_constants_and_chain_table_shapes(hostcheck):
+    """The constants the row-form product (poseidon_chain.hpp row::mul) is built on, against big-integer arithmetic: ni = -r^-1 mod 2^261 and t = r - 2^254
+    in radix 2^29 (r = Pallas Fr); and the chain tables of the transcript parameters have the documented shapes, every limb below
+    2^29, wave B's table zero exactly where q < p + 2."""
+    r = pyref.P_PALLAS; X = 1 << 29
+    ni = (-pow(r, -1, X ** 9)) % (X ** 9); t = r - (1 << 254)
+    k = hostcheck.row_consts()
+    assert [int(x) for x in k[:9]] == [(ni >> (29 * i)) & (X - 1) for i in range(9)]
+    assert [int(x) for x in k[9:]] == [(t >> (29 * i)) & (X - 1) for i in range(5)] and t < (1 << (29 * 5))
+    h = hostcheck.params(1)
+    a, g, w = (hostcheck.chain_table(h, i) for i in range(3))
+    assert a.shape == (64 * 64,) and g.shape == (64 * 9 * 64,) and w.shape == (64 * 16 * 9,)
+    assert int(max(a.max(), g.max(), w.max())) < X
+    g = g.reshape(64, 9, 64)
+    for p in range(64):
+        assert not g[p, :, :min(p + 2, 64)].any()                       # lane q < p + 2 takes nothing from y_p on wave B
+        if p + 2 < 64: assert g[p, :, p + 2:].any()
+    a = a.reshape(64, 4, 16)
+    assert not a[:, 0].any() and not a[:, 3].any() and not a[:, :, 9:].any() and not a[63, 2].any()   # rows 0 and 3 unused, limbs 9..15 zero, no Gamma after the last round
+    hostcheck.params_free(h)
