@@ -19,7 +19,7 @@
 // The waves talk through LDS mailboxes and monotonic counters (no barrier inside the 64 rounds).
 // The eight FULL rounds keep the state in row form on all five waves (element e on row e & 3 of wave e >> 2): the 17 S-boxes run at once as
 // row-form products whose broadcast operand is each row's own (ds_swizzle); the dense rows stay one-lane work on waves 0..2.
-// 75 us per permutation (142 us on one wave).  The same field values as the reference's dense rounds: the host model below
+// 73 us per permutation (142 us on one wave).  The same field values as the reference's dense rounds: the host model below
 // (chain_partial_model) is checked against permute_dense in tests/test_hostcheck.py, the kernel against the oracle on the GPU.
 #pragma once
 #include "fr.hpp"
