@@ -188,14 +188,14 @@ def test_commit_and_query_phases_at_2pow26_accepted_by_reference_verifier(gpu_ct
     assert gpu_ctx.deep_fri_verify(prm, bytes(bad)) is False
 
 
-# Opt-in (about 6 GPU-minutes: 2^22 dependent permutations per column): defined only under STARK_LONG_TESTS=1, so that the default selection has nothing
+# Opt-in (about 5 GPU-minutes: 2^22 dependent permutations per column): defined only under STARK_LONG_TESTS=1, so that the default selection has nothing
 # skipped; the recorded run is profiles/r03_prove_2pow26_end_to_end.json.
 if os.environ.get("STARK_LONG_TESTS") == "1":
     def test_end_to_end_prove_2pow26_from_trace_columns(gpu_ctx, oracle):
         """configs[4]'s trace size END TO END on one GPU: `stark_deep_fri_prove_dev` from four 2^26-row columns (8 GiB of trace; DeepAliRealBuilder's
         serial sponges, merge, commit, 40 queries).  No oracle golden exists at this size (the oracle would need about seven hours): the proof must be
         accepted by the oracle's verifier restatement and by the product's, with the size estimate agreeing and a flipped bit rejected by both.
-        (Exact bytes at scale are pinned by the 2^24 golden; this run shows the path at configs[4]'s size: 366 s, 365 s of it the column sponges.)"""
+        (Exact bytes at scale are pinned by the 2^24 golden; this run shows the path at configs[4]'s size: 305 s, 304 s of it the column sponges.)"""
         import torch
         lg, r, sched = 26, 40, [16, 16, 8]
         n0 = 1 << lg
