@@ -64,7 +64,7 @@ def test_library_communicator_on_private_stream_context_is_bracketed():
         ctx.close()
 
 
-@pytest.mark.parametrize("k,B", [(10, 5), (16, 16)])
+@pytest.mark.parametrize("k,B", [(10, 5), (16, 16), (11, 70)])
 def test_batch_prove_equals_single_proves(gpu_ctx, oracle, k, B):
     """stark_deep_fri_prove_batch_dev: B independent traces in one call (the reference's bench proves one after another,
     channel/benches/end_to_end.rs:229-309).  Each proof is byte-equal to the single prove of its trace (and, at 2^10, to the
@@ -94,10 +94,10 @@ def test_batch_prove_equals_single_proves(gpu_ctx, oracle, k, B):
     gpu_ctx.deep_fri_prove_batch_dev(traces[:1], n0, prm)   # warm the batch path
     t0 = time.perf_counter(); got = gpu_ctx.deep_fri_prove_batch_dev(traces, n0, prm); t_batch = time.perf_counter() - t0
     assert len(got) == B and got[0][0] == one
-    for p in (range(B) if k <= 12 else (1, B // 2, B - 1)):
+    for p in (range(B) if B <= 8 else (1, B // 2, B - 1)):          # B = 70: 280 chains, more workgroups than the chip holds at once
         assert got[p][0] == single(p), f"trace {p}"
     assert len({g[0] for g in got}) == B                    # different traces, different proofs
-    if k == 10:
+    if k == 10 and B <= 8:
         host_cols = [[c.cpu().numpy().view("uint64") for c in cols] for cols in keep]
         for p in range(B):
             ref = oracle.deep_fri_prove(*host_cols[p], n0, sched, r, seed_z)
@@ -203,11 +203,12 @@ def test_library_sharded_lde_one_rank_equals_single_gpu_lde(gpu_ctx, oracle, fie
     gpu_ctx._chk(gpu_ctx.lib.stark_lde_sharded_dev(gpu_ctx.h, field, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(a.data_ptr())))
     gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, field, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(b.data_ptr())))
     assert bool((a == b).all())
+    del a, b, x; gpu_ctx.trim()
     if log_n <= 13:
         assert (a.cpu().numpy().view(np.uint64) == oracle.lde(field, host, lb, shift)).all()
 
 
-@pytest.mark.parametrize("W,log_n,lb", [(2, 6, 2), (2, 12, 3), (4, 12, 3), (8, 14, 3), (4, 21, 2), (8, 20, 3)])
+@pytest.mark.parametrize("W,log_n,lb", [(2, 6, 2), (2, 12, 3), (4, 12, 3), (8, 14, 3), (4, 21, 2), (8, 20, 3), (2, 21, 3), (8, 23, 3)])
 def test_library_sharded_lde_emulated_ranks_equal_single_gpu_lde(gpu_ctx, W, log_n, lb):
     """The index arithmetic of stark_lde_sharded_dev for W > 1 (packs, per-peer chunks, global row / column offsets, the coset interleave) checked on one
     GPU: stark_diag_lde_sharded_emulated_dev runs the SAME phase code for W virtual ranks and does every exchange as device copies; the concatenated
@@ -223,3 +224,4 @@ def test_library_sharded_lde_emulated_ranks_equal_single_gpu_lde(gpu_ctx, W, log
     gpu_ctx._chk(gpu_ctx.lib.stark_diag_lde_sharded_emulated_dev(gpu_ctx.h, 0, W, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(a.data_ptr())))
     gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, 0, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(b.data_ptr())))
     assert bool((a == b).all())
+    del a, b, x; gpu_ctx.trim()
