@@ -76,6 +76,7 @@ int32_t stark_ctx_sync(stark_ctx_t* ctx);
 int32_t stark_ctx_trim(stark_ctx_t* ctx);     /* also drops the NTT plans (direct twiddle tables) and the NTT scratch vector */
 /* Tuning / diagnostic options — explicit state of the context, never read from the environment:
  *   "ntt_direct_max_log" (default 24: one-product twiddle tables up to 2^24 points; 0 = always the two-level lookup),
+ *   "ntt_merged_coset" (default 1: a coset transform's pre-scale is folded into its first pass's twiddle table; 0 = separate tables),
  *   "ntt_log_tile" (8..12, default 11; -1 restores the default), "ntt_min_waves" (2 | 4), "poseidon_lane_only" (0 | 1).
  * Changing an option synchronises the stream and drops the cached NTT plans. */
 int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value);

@@ -268,7 +268,7 @@ class Context:
         self._chk(self.lib.stark_ctx_sync(self.h))
 
     def set_option(self, key: str, value: int):
-        """stark_ctx_set_option: "ntt_direct_max_log", "ntt_log_tile", "ntt_min_waves", "poseidon_lane_only"."""
+        """stark_ctx_set_option: "ntt_direct_max_log", "ntt_merged_coset", "ntt_log_tile", "ntt_min_waves", "poseidon_lane_only"."""
         self._chk(self.lib.stark_ctx_set_option(self.h, key.encode(), value))
 
     def trim(self):

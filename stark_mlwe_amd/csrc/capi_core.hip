@@ -330,7 +330,7 @@ int32_t ctx_aux(stark_ctx* ctx, size_t k, stark_ctx** out) {
         ctx->aux.push_back(a);
     }
     stark_ctx* a = ctx->aux[k];
-    a->opt_ntt_direct_max_log = ctx->opt_ntt_direct_max_log; a->opt_ntt_log_tile = ctx->opt_ntt_log_tile; a->opt_ntt_log_tile_forced = ctx->opt_ntt_log_tile_forced;
+    a->opt_ntt_direct_max_log = ctx->opt_ntt_direct_max_log; a->opt_ntt_merged_coset = ctx->opt_ntt_merged_coset; a->opt_ntt_log_tile = ctx->opt_ntt_log_tile; a->opt_ntt_log_tile_forced = ctx->opt_ntt_log_tile_forced;
     a->opt_ntt_min_waves = ctx->opt_ntt_min_waves; a->opt_poseidon_lane_only = ctx->opt_poseidon_lane_only; a->opt_sponge_one_wave = ctx->opt_sponge_one_wave;
     *out = a; return STARK_OK;
 }
@@ -343,10 +343,11 @@ int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value) {
     if (k == "ntt_direct_max_log") { if (value < 0 || value > 30) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_direct_max_log: 0..30"); ctx->opt_ntt_direct_max_log = (int)value; }
     else if (k == "ntt_log_tile") { if (value != -1 && (value < 8 || value > 12)) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_log_tile: 8..12, or -1 for the default"); ctx->opt_ntt_log_tile_forced = value != -1; ctx->opt_ntt_log_tile = value == -1 ? 11 : (int)value; }
     else if (k == "ntt_min_waves") { if (value != 2 && value != 4) return ctx->fail(STARK_ERR_INVALID_ARG, "ntt_min_waves: 2 or 4"); ctx->opt_ntt_min_waves = (int)value; }
+    else if (k == "ntt_merged_coset") ctx->opt_ntt_merged_coset = value != 0;
     else if (k == "poseidon_lane_only") ctx->opt_poseidon_lane_only = value != 0;
     else if (k == "sponge_one_wave") ctx->opt_sponge_one_wave = value != 0;
     else if (k == "sponge_debug") ctx->opt_sponge_debug = (int)value;
-    else return ctx->fail(STARK_ERR_INVALID_ARG, "unknown option '" + k + "' (ntt_direct_max_log, ntt_log_tile, ntt_min_waves, poseidon_lane_only)");
+    else return ctx->fail(STARK_ERR_INVALID_ARG, "unknown option '" + k + "' (ntt_direct_max_log, ntt_merged_coset, ntt_log_tile, ntt_min_waves, poseidon_lane_only, sponge_one_wave)");
     STARK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     stark::ntt_plans_free(ctx);                  // plans (and their direct tables) are rebuilt lazily under the new options
     return STARK_OK;

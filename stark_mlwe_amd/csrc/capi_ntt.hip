@@ -21,6 +21,8 @@ struct NttPlan {
     bool have_coset = false; fr_t coset; DevTable coset_tab;
     // direct tables (log_n <= 24): inter-pass twiddles of the strided passes, coset pre-scale
     fr_t* tw_direct[2] = {nullptr, nullptr}; fr_t* coset_direct = nullptr;
+    // merged form for plans with a strided first pass: (g^S)^p by point + the first pass's twiddles times g^rest (one full-length table read less per element)
+    fr_t* coset_small = nullptr; fr_t* tw_coset_direct = nullptr;
     // power tables of coset shifts used by the multi-GPU column phase (a handful: the 2^log_blowup cosets of an LDE)
     std::vector<std::pair<fr_t, DevTable>> shift_tabs;
     // plain (c0 = 1) power tables for the element-wise kernels of stark_ntt_rows_coset_dev: coset shifts, and w_N itself (key = one)
@@ -30,6 +32,7 @@ struct NttPlan {
         for (auto& st : plain_tabs) { if (st.second.lo) (void)hipFree(st.second.lo); if (st.second.hi) (void)hipFree(st.second.hi); }
         for (auto p : tw_direct) if (p) (void)hipFree(p);
         if (coset_direct) (void)hipFree(coset_direct);
+        if (coset_small) (void)hipFree(coset_small); if (tw_coset_direct) (void)hipFree(tw_coset_direct);
         for (auto p : stage_tw) if (p) (void)hipFree(p);
         if (root.lo) (void)hipFree(root.lo); if (root.hi) (void)hipFree(root.hi); if (scale) (void)hipFree(scale);
         if (coset_tab.lo) (void)hipFree(coset_tab.lo); if (coset_tab.hi) (void)hipFree(coset_tab.hi);
@@ -126,6 +129,7 @@ static int32_t launch_any(stark_ctx* ctx, NttPassArgs A, uint64_t total_elems, b
 template <class F> static int32_t launch_strided(stark_ctx* ctx, const NttPassArgs& A, uint64_t total_elems, const fr_t* src, fr_t* dst) { return launch_any<F, true>(ctx, A, total_elems, A.pre_direct || A.pre.lo, src, dst); }
 template <class F> static int32_t launch_last(stark_ctx* ctx, const NttPassArgs& A, uint64_t total_elems, const fr_t* src, fr_t* dst) { return launch_any<F, false>(ctx, A, total_elems, A.pre.lo != nullptr, src, dst); }
 
+template <class F> static int32_t plain_table(stark_ctx* ctx, NttPlan* big, const fr_t& base, int log_n, PowTable* out);   // plain (c0 = 1) power tables, defined below
 // `batch` vectors of 2^log_n elements each, contiguous.  data is transformed in place (scratch from the context).
 template <class F>
 static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bool inverse, const fr_t* coset, const fr_t* scale_override_dev, int log_nonzero = -1) {
@@ -144,13 +148,29 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
             else STARK_TRY(fill_table<F>(ctx, fr_inv<F>(*coset), x32<F>(fr_inv<F>(fr_from_u64<F>(1ull << log_n))), lo_bits, hi_bits, p->coset_tab));   // n^-1 g^-k
             p->coset = *coset; p->have_coset = true;
             if (p->coset_direct) { (void)hipFree(p->coset_direct); p->coset_direct = nullptr; }
-            if (!inverse && ntt_direct_max(ctx) >= log_n && hipMalloc((void**)&p->coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess)
-                hipLaunchKernelGGL(k_fill_pow_direct<F>, dim3((unsigned)((((uint64_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, p->coset_tab.view(), 1ull << log_n, p->coset_direct);
-            else (void)hipGetLastError();
+            if (p->coset_small) { (void)hipFree(p->coset_small); p->coset_small = nullptr; }
+            if (p->tw_coset_direct) { (void)hipFree(p->tw_coset_direct); p->tw_coset_direct = nullptr; }
+            bool merged = false;
+            if (!inverse && p->P >= 2 && p->tw_direct[0] && ctx->opt_ntt_merged_coset && ntt_direct_max(ctx) >= log_n) {
+                // merged tables: the pre-scale's g^rest goes into the first pass's twiddle table, what is left is (g^S)^p by point index
+                PowTable gplain; STARK_TRY(plain_table<F>(ctx, p, *coset, log_n, &gplain));
+                const int lb0 = p->log_b[0], ls = log_n - lb0;
+                if (hipMalloc((void**)&p->coset_small, ((size_t)1 << lb0) * sizeof(fr_t)) == hipSuccess && hipMalloc((void**)&p->tw_coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess) {
+                    hipLaunchKernelGGL(k_fill_coset_merged<F>, dim3((unsigned)((((uint64_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, p->coset_tab.view(), gplain, (const fr_t*)p->tw_direct[0], ls, lb0, p->coset_small, p->tw_coset_direct);
+                    merged = hipGetLastError() == hipSuccess;
+                }
+                if (!merged) { (void)hipGetLastError(); if (p->coset_small) { (void)hipFree(p->coset_small); p->coset_small = nullptr; } if (p->tw_coset_direct) { (void)hipFree(p->tw_coset_direct); p->tw_coset_direct = nullptr; } }
+            }
+            if (!merged) {
+                if (!inverse && ntt_direct_max(ctx) >= log_n && hipMalloc((void**)&p->coset_direct, ((size_t)1 << log_n) * sizeof(fr_t)) == hipSuccess)
+                    hipLaunchKernelGGL(k_fill_pow_direct<F>, dim3((unsigned)((((uint64_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, p->coset_tab.view(), 1ull << log_n, p->coset_direct);
+                else (void)hipGetLastError();
+            }
         }
         if (!inverse) pre = p->coset_tab.view(); else post = p->coset_tab.view();
     }
     const fr_t* pre_direct = (coset && !inverse) ? p->coset_direct : nullptr;
+    const bool merged = coset && !inverse && p->coset_small && p->tw_coset_direct;
     const uint64_t total = batch << log_n;
     fr_t* scratch = nullptr;
     if (p->P > 1) { void* s = nullptr; STARK_TRY(ctx_scratch(ctx, total * sizeof(fr_t), &s)); scratch = (fr_t*)s; }
@@ -162,12 +182,14 @@ static int32_t ntt_run(stark_ctx* ctx, fr_t* data, int log_n, uint64_t batch, bo
         A.log_b = p->log_b[i]; A.log_m = rem; A.stride = 1ull << (rem - A.log_b);
         A.log_c = pick_log_c(ctx, A.log_b, rem - A.log_b, log_n);
         A.stage_tw = p->stage_tw[i]; A.pre = (i == 0) ? pre : none; A.pre_direct = (i == 0) ? pre_direct : nullptr; A.tw_direct = p->tw_direct[i];
+        A.pre_small = nullptr;
+        if (i == 0 && merged) { A.pre_small = p->coset_small; A.tw_direct = p->tw_coset_direct; }
         // zero-padded input (LDE): element j is non-zero only for j < 2^log_nonzero; in the first strided pass that is the points p < 2^log_nonzero / stride
         A.nz_points = (i == 0 && log_nonzero >= 0 && log_nonzero < log_n && (1ull << log_nonzero) >= A.stride) ? (uint32_t)((1ull << log_nonzero) / A.stride) : 0u;
         STARK_TRY(launch_strided<F>(ctx, A, total, src, scratch));
         src = scratch; rem -= A.log_b;
     }
-    A.pre = (p->P == 1) ? pre : none; A.pre_direct = nullptr; A.tw_direct = nullptr; A.nz_points = 0;
+    A.pre = (p->P == 1) ? pre : none; A.pre_direct = nullptr; A.pre_small = nullptr; A.tw_direct = nullptr; A.nz_points = 0;
     A.log_b = p->log_b[p->P - 1]; A.stage_tw = p->stage_tw[p->P - 1];
     A.log_b1 = p->P >= 2 ? p->log_b[0] : 0; A.log_b2 = p->P == 3 ? p->log_b[1] : 0;
     A.log_c = p->P == 1 ? 0 : pick_log_c(ctx, A.log_b, A.log_b1, log_n);

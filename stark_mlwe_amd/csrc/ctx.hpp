@@ -78,6 +78,7 @@ struct stark_ctx {
 
     // tuning / diagnostic options (stark_ctx_set_option): explicit API state, never the environment
     int opt_ntt_direct_max_log = 24;     // direct (one-product) twiddle / coset tables for transforms up to 2^this (0 disables)
+    bool opt_ntt_merged_coset = true;    // coset transforms: the pre-scale folded into the first pass's twiddle table (one table read instead of two); 0 = separate tables (comparison)
     int opt_ntt_log_tile = 11;           // log2 of the elements of an NTT tile (8..12); -1 would mean "auto" (the default also shrinks for small launches)
     bool opt_ntt_log_tile_forced = false;
     int opt_ntt_min_waves = 2;           // occupancy hint of the NTT kernels (2 or 4 waves per SIMD)

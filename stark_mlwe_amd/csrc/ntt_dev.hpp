@@ -55,6 +55,9 @@ struct NttPassArgs {
     // Direct tables (plans up to 2^24 points): one product per element instead of the two of the two-level lookup.
     const fr_t* tw_direct;   // strided pass: w_m^(rest*k) at index k*stride + rest (the layout of the sub-problem); nullptr => `root` lookup
     const fr_t* pre_direct;  // first pass: g^j at index j; nullptr => `pre` lookup
+    const fr_t* pre_small;   // first strided pass of a coset transform, merged form: (g^S)^p by POINT index p (2^log_b entries, cache-resident); the other factor
+                             // g^rest of g^(pS + rest) is common to a column and sits in that pass's twiddle table (tw_direct = w_m^(rest k) g^rest): one
+                             // full-length table read per element less than with pre_direct
     uint32_t nz_points;      // first pass of a zero-padded transform (LDE): only the points p < nz_points of every sub-NTT are non-zero
                              // in memory; the rest is taken as zero without being read (0 = all points are read)
     uint32_t dlimb[9];       // 4r in borrow-proof nine-limb form (fr29.hpp ntt29_offset)
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttP
                     for (int i = 0; i < 9; ++i) x.l[i] = 0;
                 } else {
                     const uint64_t g = J.base + (uint64_t)p * A.stride + c;
-                    const fr_t m = A.pre_direct ? ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1)))
+                    const fr_t m = A.pre_small ? ldg(A.pre_small + p) : A.pre_direct ? ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1)))
                                                 : pow_lookup<F>(A.pre, A.pre_row_stride ? (uint64_t)p * A.pre_row_stride + A.rest0 + (J.tile << A.log_c) + c : g);
                     x = fr29_mul_mont<F>(fr29_unpack(m), fr29_unpack(ldg(src + g)));
                 }
@@ -320,6 +323,15 @@ __global__ void k_rows_twiddle(fr_t* __restrict__ y, PowTable root, uint64_t nro
     const uint64_t i = t >> log_cols, m = t & ((1ull << log_cols) - 1);
     const uint64_t e = ((row0 + i) * m) & ((1ull << log_n) - 1);
     if (e) stg(y + t, fr_mul<F>(ldg(y + t), pow_lookup<F>(root, e)));
+}
+// merged coset tables of a plan's first strided pass: small[p] = c32 (g^S)^p;  twc[k S + rest] = tw[k S + rest] * g^rest  (tw carries the factor 32 already)
+template <class F>
+__global__ void k_fill_coset_merged(PowTable g32, PowTable gplain, const fr_t* __restrict__ tw, int log_s, int log_b, fr_t* __restrict__ small, fr_t* __restrict__ twc) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (1ull << log_b)) stg(small + i, pow_lookup<F>(g32, i << log_s));
+    if (i >> (log_s + log_b)) return;
+    const uint64_t rest = i & ((1ull << log_s) - 1);
+    stg(twc + i, rest ? fr_mul<F>(ldg(tw + i), pow_lookup<F>(gplain, rest)) : ldg(tw + i));
 }
 template <class F>
 __global__ void k_zero_fill(fr_t* p, uint64_t n) {

@@ -203,9 +203,10 @@ def test_library_sharded_lde_one_rank_equals_single_gpu_lde(gpu_ctx, oracle, fie
     gpu_ctx._chk(gpu_ctx.lib.stark_lde_sharded_dev(gpu_ctx.h, field, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(a.data_ptr())))
     gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, field, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(b.data_ptr())))
     assert bool((a == b).all())
+    got = a.cpu().numpy().view(np.uint64) if log_n <= 13 else None
     del a, b, x; gpu_ctx.trim()
     if log_n <= 13:
-        assert (a.cpu().numpy().view(np.uint64) == oracle.lde(field, host, lb, shift)).all()
+        assert (got == oracle.lde(field, host, lb, shift)).all()
 
 
 @pytest.mark.parametrize("W,log_n,lb", [(2, 6, 2), (2, 12, 3), (4, 12, 3), (8, 14, 3), (4, 21, 2), (8, 20, 3), (2, 21, 3), (8, 23, 3)])
@@ -225,3 +226,31 @@ def test_library_sharded_lde_emulated_ranks_equal_single_gpu_lde(gpu_ctx, W, log
     gpu_ctx._chk(gpu_ctx.lib.stark_lde_dev(gpu_ctx.h, 0, C.c_void_p(x.data_ptr()), log_n, lb, _ptr(shift), C.c_void_p(b.data_ptr())))
     assert bool((a == b).all())
     del a, b, x; gpu_ctx.trim()
+
+
+@pytest.mark.parametrize("field,log_n", [(0, 12), (0, 14), (0, 17), (0, 22), (1, 14), (1, 22)])
+def test_coset_ntt_with_merged_tables_equals_separate_tables_and_oracle(gpu_ctx, oracle, field, log_n):
+    """A coset transform of two or more passes reads ONE table in its first pass (pre-scale folded into the twiddles, ntt_dev.hpp k_fill_coset_merged);
+    option "ntt_merged_coset" = 0 keeps the separate pre-scale and twiddle tables: same values both ways, and the oracle's coset NTT at 2^12 / 2^14."""
+    import numpy as np
+    import torch
+    from stark_mlwe_amd.api import _ptr
+    n = 1 << log_n; lib = gpu_ctx.lib
+    x = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx._chk(lib.stark_synth_column_dev(gpu_ctx.h, 31 + log_n, 2, 0, n, C.c_void_p(x.data_ptr())))      # below 2^254: valid in both fields
+    host = x.cpu().numpy().view(np.uint64) if log_n <= 14 else None
+    shift = oracle.from_u64(5 if field == 0 else 7, field)
+    outs = []
+    try:
+        for merged in (1, 0):
+            gpu_ctx._chk(lib.stark_ctx_set_option(gpu_ctx.h, b"ntt_merged_coset", merged))
+            y = x.clone()
+            for _ in range(2):      # second call: the cached plan
+                y.copy_(x); gpu_ctx._chk(lib.stark_ntt_dev(gpu_ctx.h, field, C.c_void_p(y.data_ptr()), log_n, 0, _ptr(shift)))
+            outs.append(y)
+    finally:
+        gpu_ctx._chk(lib.stark_ctx_set_option(gpu_ctx.h, b"ntt_merged_coset", 1))
+    assert bool((outs[0] == outs[1]).all())
+    if host is not None:
+        assert (outs[0].cpu().numpy().view(np.uint64) == oracle.ntt(field, host, coset=shift)).all()
+    del outs, x, y; gpu_ctx.trim()
