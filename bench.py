@@ -163,7 +163,8 @@ def main():
         return torch.empty((rows, 4), dtype=torch.int64, device=dev)
 
     # synthetic trace: columns 0..3; this rank holds rows [rank*n, (rank+1)*n) of the world*n-row trace (DESIGN.md "Synthetic inputs")
-    seed = args.synth_seed if args.synth_seed is not None else 0x5EED0000 + log_n
+    log_total = log_n + (world.bit_length() - 1)     # the whole trace: 2^log_n rows per GPU
+    seed = args.synth_seed if args.synth_seed is not None else 0x5EED0000 + log_total    # at N = 1 the seed of tests/golden/step_roots_k{log_n}.json
     cols = [dbuf(n) for _ in range(4)]
     for c in range(4):
         ctx._chk(lib.stark_synth_column_dev(ctx.h, seed, c, rank * n, n, C.c_void_p(cols[c].data_ptr())))
@@ -182,11 +183,12 @@ def main():
             # failed inside LibComm() while its peers already sat in ncclCommInitRank would hang the job.
             flag = torch.tensor([1 if lib.stark_comm_available(None) == 0 else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                sd.set_comm(sd.LibComm(ctx, rank, world))
-            elif rank == 0:
-                sys.stderr.write("[bench] library communicator unavailable on some rank; every rank uses torch.distributed's RCCL (same exchanges)\n")
-        job = sd.ShardedTrace(sd.HipProvider(ctx, device=dev), log_n + (world.bit_length() - 1), LOG_BLOWUP, SCHEDULE, SEED_Z, coset, z)
+            lc, comm_used = sd.checked_lib_comm(ctx, rank, world, dev, int(flag.item()) == 1)
+            if lc is not None:
+                sd.set_comm(lc)
+            if rank == 0:
+                sys.stderr.write(f"[bench] collectives: {comm_used}\n")
+        job = sd.ShardedTrace(sd.HipProvider(ctx, device=dev), log_total, LOG_BLOWUP, SCHEDULE, SEED_Z, coset, z)
 
         def step():
             return job.step(cols)
@@ -222,11 +224,11 @@ def main():
         "vs_baseline": None,
         "dtype": "u256 (4x u64 Montgomery limbs, Pallas Fr)",
         "data": "synthetic",
-        "config": {"workload": f"one 2^{log_n + (world.bit_length() - 1)}-row trace x 4 columns (2^{log_n} rows per GPU), blowup 8: LDE (iNTT + coset NTT) + DEEP-ALI merge + FRI folds + Poseidon leaf hashes + Poseidon-Merkle trees (schedule [16,16,8]), kernels only",
+        "config": {"workload": f"one 2^{log_total}-row trace x 4 columns (2^{log_n} rows per GPU), blowup 8: LDE (iNTT + coset NTT) + DEEP-ALI merge + FRI folds + Poseidon leaf hashes + Poseidon-Merkle trees (schedule [16,16,8]), kernels only",
                    "log_trace_per_gpu": log_n, "log_blowup": LOG_BLOWUP, "schedule": SCHEDULE, "field": "pallas_fr", "sharding": sharding},
         "roots": roots_hex(roots),
     }
-    gold = golden_step_roots(log_n, seed) if world == 1 else None
+    gold = golden_step_roots(log_total, seed)      # N > 1: the sharded step commits to the same 2^log_total-row trace as one GPU would (same roots)
     # True / False against the committed oracle golden of exactly this step; null when no golden exists for this size, seed or N
     out["roots_match_golden"] = None if gold is None else (out["roots"] == gold)
     if args.steps_only:

@@ -166,6 +166,33 @@ class LibComm:
         self.lib.stark_comm_destroy(self.ctx.h)
 
 
+def checked_lib_comm(ctx, rank, nranks, dev, all_ranks_can_bind=True):
+    """A LibComm that has passed one all-to-all and one all-gather against torch.distributed on the same bytes, or None — decided by ALL ranks
+    together (all_reduce MIN), so that every rank ends up on the same transport.  The multi-rank branch of stark_comm_* cannot run on a
+    one-GPU box; a job checks it once at start-up before its data path depends on it.  Returns (comm or None, a line for the log)."""
+    if not all_ranks_can_bind:
+        return None, "torch.distributed RCCL (library communicator unavailable on some rank)"
+    lc, ok = None, 0
+    try:
+        lc = LibComm(ctx, rank, nranks)
+        probe = (torch.arange(nranks * 256 * 4, dtype=torch.int64, device=dev) * 0x9E3779B97F4A7C15 + rank * 0x1234567).view(nranks * 256, 4)
+        want = torch.empty_like(probe)
+        dist.all_to_all_single(want.view(-1), probe.contiguous().view(-1))
+        got = lc.all_to_all(probe)
+        gath = lc.all_gather(probe[:4])
+        ok = int(bool((got == want).all()) and bool((gath[4 * rank:4 * rank + 4] == probe[:4]).all()))
+    except Exception as ex:      # noqa: BLE001 — reported, the job continues on torch.distributed
+        import sys
+        sys.stderr.write(f"[stark_mlwe_amd.dist] rank {rank}: library communicator failed its start-up check: {ex!r}\n")
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return lc, "library RCCL communicator (stark_comm_*), checked against torch.distributed at start-up"
+    if lc is not None:
+        lc.close()
+    return None, "torch.distributed RCCL (library communicator failed its start-up check on some rank)"
+
+
 _COMM = TorchComm()
 
 

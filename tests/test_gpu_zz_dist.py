@@ -221,3 +221,40 @@ def test_rccl_collectives_accept_our_tensors():
     p.start()
     res = _collect([p], q, 1, "rccl one-rank", limit_s=240)[0]
     assert res == (True, True, True, True, 1.5), res
+
+
+def _checked_comm_worker(port, q):
+    _rendezvous_env(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import ctypes as C
+        from stark_mlwe_amd.api import Context
+        from stark_mlwe_amd import dist as sd
+        dev = torch.device("cuda", 0)
+        ctx = Context(0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        lc, msg = sd.checked_lib_comm(ctx, 0, 1, dev, True)
+        none, msg2 = sd.checked_lib_comm(ctx, 0, 1, dev, False)
+        ok = lc is not None and msg.startswith("library RCCL") and none is None and "unavailable" in msg2
+        if lc is not None:
+            x = (torch.arange(64 * 4, dtype=torch.int64, device=dev) * 7 + 3).view(64, 4)
+            ok = ok and bool((lc.all_to_all(x) == x).all()) and bool((lc.all_reduce_sum(x) == x).all())
+            lc.close()
+        ctx.close()
+        q.put((ok, msg))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        q.put(("error", repr(ex), traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_communicator_start_up_check_against_torch_distributed():
+    """bench.py's N > 1 start-up: the library's RCCL communicator is adopted only after one all-to-all / all-gather agreed with
+    torch.distributed's on the same bytes, the ranks deciding together (here: the one rank a one-GPU box allows)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_checked_comm_worker, args=(31900 + os.getpid() % 1000, q))
+    p.start()
+    res = _collect([p], q, 1, "checked lib comm", limit_s=240)[0]
+    assert res[0] is True, res

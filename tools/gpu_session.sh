@@ -29,5 +29,5 @@ pmc sqb "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 
 timeout -k 10 200 python tools/sponge_timing.py 2>/dev/null | grep log_n0 > $OUT/sponge_timing_$R.jsonl; cat $OUT/sponge_timing_$R.jsonl
 timeout -k 10 200 python tools/sponge_debug_timing.py 2>/dev/null | grep dbg > $OUT/sponge_breakdown_$R.jsonl
 [ -x tools/bin/chain_row ] && (cd tools && ./bin/chain_row 2000 > $OUT/chain_row_$R.txt && python3 chain_row_check.py $OUT/chain_row_$R.txt | tail -1; ./bin/chain_bench > $OUT/chain_bench_$R.txt 2>&1)
-(STARK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 1 --warmup 1 --log-trace 16 --no-cpu-baseline > $OUT/bench2_gloo_$R.json 2> $OUT/bench2_gloo_$R.err; echo "bench2 exit $?"; cut -c1-300 $OUT/bench2_gloo_$R.json)
+(STARK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 1 --warmup 1 --log-trace 19 --no-cpu-baseline > $OUT/bench2_gloo_$R.json 2> $OUT/bench2_gloo_$R.err; echo "bench2 exit $?"; cut -c1-300 $OUT/bench2_gloo_$R.json)
 echo "session done"
