@@ -20,6 +20,17 @@ static inline int poseidon_block(int t) { return (size_t)t * 32 * 64 <= kMaxLds 
 static inline size_t poseidon_lds(int t, int block) { return (size_t)t * 32 * block; }
 // the wave-pair kernels (poseidon_pair.hpp) serve the hot widths; the "poseidon_lane_only" option selects the one-lane-per-sponge form (diagnostic)
 static inline bool use_pair(const stark_ctx* ctx, int t) { return !ctx->opt_poseidon_lane_only && (t == 9 || t == 17); }
+// Small batches of t = 17 sponges take the five-wave latency form of poseidon_chain.hpp (one workgroup per sponge, one resident per CU): Merkle levels of up
+// to 256 nodes (two permutations: 155 us against 290 us on one wave each; equal from 512 nodes on), leaf layers of up to 2048 leaves (one permutation:
+// 80 us per 256 leaves against the 0.77 ms a launch of the wave-pair throughput kernel takes whatever its size).  tools/latency_timing.py;
+// option "sponge_one_wave" keeps them on the one-wave / wave-pair kernels (comparison).
+constexpr size_t kChainMaxNodes = 256, kChainMaxLeaves = 2048;
+static inline bool use_chain(const stark_ctx* ctx, const PoseidonDev& d, size_t n, size_t n_max) {
+    return !ctx->opt_poseidon_lane_only && !ctx->opt_sponge_one_wave && d.t == 17 && d.rf == 8 && d.rp == 64 && d.chain_a && n <= n_max;
+}
+static inline row::Consts row_consts_of(const stark_ctx* ctx) {
+    const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i]; RK.dbg = (uint32_t)ctx->opt_sponge_debug; return RK;
+}
 
 namespace stark {
 
@@ -174,7 +185,7 @@ int32_t tr_hash_dev(stark_ctx* ctx, const char* tag, const fr_t* fields_dev, siz
 // Long serial sponges: five waves per chain (poseidon_chain.hpp) unless the option "sponge_one_wave" asks for the round-2 one-wave form.
 static int32_t launch_column_sponges(stark_ctx* ctx, stark_params* tp, const TrMultiJob& J, unsigned nblocks, fr_t* out_dev) {
     if (tp->dev.chain_a && !ctx->opt_sponge_one_wave) {
-        const RowConstsHost h = row_consts_host(); row::Consts RK; for (int i = 0; i < 9; ++i) RK.ni[i] = h.ni[i]; for (int i = 0; i < 5; ++i) RK.t[i] = h.t[i]; RK.dbg = (uint32_t)ctx->opt_sponge_debug;
+        const row::Consts RK = row_consts_of(ctx);
         hipLaunchKernelGGL(k_tr_hash_chain, dim3(nblocks), dim3(320), chain_lds_bytes(), ctx->stream, tp->dev, J, RK, out_dev);
     } else {
         hipLaunchKernelGGL(k_tr_hash_coop_multi, dim3(nblocks), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, J, out_dev);
@@ -269,6 +280,8 @@ int32_t stark_ctx_create(int32_t device, void* stream, stark_ctx_t** out) {
     (void)hipFuncSetAttribute((const void*)k_hash_ds2<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_hash_ds2<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     (void)hipFuncSetAttribute((const void*)k_tr_hash_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_hash_ds_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    (void)hipFuncSetAttribute((const void*)k_leaf_pair_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     *out = c; return STARK_OK;
 }
 }  // extern "C"
@@ -476,6 +489,10 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* 
     if (chunk) J.arity = chunk;          // the verifier's groups: DS field `arity` as given, `chunk` children per hash (a short last chunk of the proof's level)
     J.n_out = mode == 1 ? n_in : (n_in + J.arity - 1) / J.arity;
     if (!J.n_out) return STARK_OK;
+    if (use_chain(ctx, p->dev, J.n_out, kChainMaxNodes)) {
+        hipLaunchKernelGGL(k_hash_ds_chain, dim3((unsigned)J.n_out), dim3(320), chain_lds_bytes(), st, p->dev, J, row_consts_of(ctx), in0, in1, out);
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
     if (use_pair(ctx, p->dev.t) && J.n_out <= 8192) {
         // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
         if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), st, p->dev, J, in0, in1, out);
@@ -537,6 +554,10 @@ int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const f
     if (!n) return STARK_OK;
     stark_params* tp = nullptr; STARK_TRY(ctx_transcript_params(ctx, &tp));
     fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
+    if (use_chain(ctx, tp->dev, n, kChainMaxLeaves)) {
+        hipLaunchKernelGGL(k_leaf_pair_chain, dim3((unsigned)n), dim3(320), chain_lds_bytes(), st, tp->dev, row_consts_of(ctx), (const fr_t*)init, f, f_next, m, h);
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
     if (use_pair(ctx, 17)) {
         hipLaunchKernelGGL(k_leaf_pair2, dim3((unsigned)((n + 63) / 64)), dim3(128), pair_lds_bytes(17), st, tp->dev, init + 17, f, f_next, n, m, h);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;

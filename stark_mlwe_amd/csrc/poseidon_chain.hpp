@@ -371,10 +371,12 @@ __device__ __forceinline__ void chain_partial_rounds(uint32_t& sr, const Poseido
     sr = valid ? C.sfin[e * 16 + cidx] : 0u;
 }
 
-// The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of five waves per chain.  Same job description as
-// k_tr_hash_coop_multi (block b: column b, or with J.batch column b & 3 of trace b >> 2).
-__global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_chain(PoseidonDev P, TrMultiJob J, row::Consts RK, fr_t* __restrict__ out) {
-    extern __shared__ uint4 lds[];
+// One sponge by the workgroup's five waves: the stream elem(0), elem(1), ... (total of them; elem is asked by lanes 0..15 of wave 0 only, for q < total)
+// into a state whose capacity element starts as `cap`, the lazy duplex of transcript/src/lib.rs:79-88 (permute only before absorbing more, once at
+// the end) — which is also hash_with_ds_dynamic's eager sponge over ds || children || 1 (crates/poseidon/src/lib.rs:219-312: the same permutations at
+// the same points, cap = 0).  Element 0 of the final state goes to *out_slot.
+template <class Elem>
+__device__ __forceinline__ void chain_sponge(const PoseidonDev& P, const row::Consts& RK, uint4* lds, size_t total, const fr_t& cap, Elem elem, fr_t* out_slot) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     CoopLds L = coop_setup<17>(lds, P);                                  // ends with a workgroup barrier
     ChainLds C;
@@ -388,18 +390,15 @@ __global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))
       if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(P.rc_partial[0]); for (int i = 0; i < 16; ++i) C.rcp0[i] = i < 9 ? u.l[i] : 0u; }
       if (threadIdx.x < 4) lds_vstore(C.flag + threadIdx.x, 0u); }
     __syncthreads();
-    const int b = blockIdx.x, c = J.batch ? (b & 3) : (J.stride ? 0 : b);
-    const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : (J.stride ? J.fields[0] + (size_t)b * J.stride : J.fields[c]);
-    const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
     const ChainPre pre = chain_preload(P, wave, lane);
     const uint32_t cidx = lane & 15; const int e = 4 * wave + (lane >> 4); const bool valid = e < 17;
     // the state in row form; element 16 starts as the capacity constant
-    if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(J.cap); for (int i = 0; i < 9; ++i) C.sfin[16 * 16 + i] = u.l[i]; }
+    if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(cap); for (int i = 0; i < 9; ++i) C.sfin[16 * 16 + i] = u.l[i]; }
     __syncthreads();
     uint32_t sr = valid ? C.sfin[e * 16 + cidx] : 0u;
     auto fetch = [&](size_t base) -> fr_t {
         const size_t q = base + lane;
-        if (wave == 0 && lane < 16 && q < total) return q < np ? ldg(prefix + q) : (q < np + kk ? ldg(fields + (q - np)) : ldg(suffix + (q - np - kk)));
+        if (wave == 0 && lane < 16 && q < total) return elem(q);
         return fr_zero<PF>();
     };
     auto permute = [&](uint32_t cbase) {
@@ -410,7 +409,7 @@ __global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))
     };
     uint32_t cbase = 0;
     fr_t nxt = fetch(0);
-    for (size_t base = 0; base < total; base += 16) {                    // the lazy duplex of transcript/src/lib.rs:79-88: permute only before absorbing more
+    for (size_t base = 0; base < total; base += 16) {
         const fr_t cur = nxt;
         if (base + 16 < total) nxt = fetch(base + 16);                   // in flight during the permutation
         if (base) { permute(cbase); cbase += 64; }
@@ -425,8 +424,43 @@ __global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))
         fr29_t v; for (int i = 0; i < 9; ++i) v.l[i] = C.sfin[i];
         fr_t s = chain_canon(v);
         if (lds_vload(C.flag + 3)) s = fr_zero<PF>();                    // a timed-out wait (never seen) must not pass for a digest
-        stg(out + b, s);
+        stg(out_slot, s);
     }
+}
+
+// The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of five waves per chain.  Same job description as
+// k_tr_hash_coop_multi (block b: column b, or with J.batch column b & 3 of trace b >> 2).
+__global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_hash_chain(PoseidonDev P, TrMultiJob J, row::Consts RK, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    const int b = blockIdx.x, c = J.batch ? (b & 3) : (J.stride ? 0 : b);
+    const fr_t* prefix = J.prefix[c]; const fr_t* suffix = J.suffix[c]; const fr_t* fields = J.batch ? J.batch[b] : (J.stride ? J.fields[0] + (size_t)b * J.stride : J.fields[c]);
+    const size_t np = J.np[c], kk = J.k[c], total = np + kk + (size_t)J.ns[c];
+    chain_sponge(P, RK, lds, total, J.cap, [&](size_t q) -> fr_t { return q < np ? ldg(prefix + q) : (q < np + kk ? ldg(fields + (q - np)) : ldg(suffix + (q - np - kk))); }, out + b);
+}
+
+// SMALL Merkle levels and leaf layers, where the launch is one permutation's latency whatever the kernel: the same five waves per NODE (72 us per
+// permutation against 142 us on one wave and ~0.4 ms in the wave-pair throughput form).  Jobs as k_hash_ds_coop / k_leaf_pair2.
+__global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_hash_ds_chain(PoseidonDev P, DsJob J, row::Consts RK, const fr_t* __restrict__ in0, const fr_t* __restrict__ in1, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    const size_t k = blockIdx.x;
+    const size_t cnt = J.mode == 1 ? 2 : ((k + 1) * J.arity <= J.n_in ? J.arity : J.n_in - k * J.arity);
+    const size_t total = 4 + cnt + 1;                                                // ds || children || 1, zero padded
+    chain_sponge(P, RK, lds, total, fr_zero<PF>(), [&](size_t q) -> fr_t {
+        if (q == 0) return J.arity_f; if (q == 1) return J.level_f; if (q == 2) return fr_from_u64<PF>(ds_position(J, k)); if (q == 3) return J.label_f;
+        if (q == total - 1) return fr_one<PF>();
+        const size_t c = q - 4; return J.mode == 1 ? ds_pair_child(J, in0, in1, k, c) : ldg(in0 + k * J.arity + c);
+    }, out + k);
+}
+// hash_leaf_pair (fri.rs:38-44): init = the 17-element template of capi_core.hip ctx_leaf_init (elements 4, 5 are the slots of f_i and s_i, element 16 the capacity)
+__global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_leaf_pair_chain(PoseidonDev P, row::Consts RK, const fr_t* __restrict__ init, const fr_t* __restrict__ f,
+                                                                                                   const fr_t* __restrict__ f_next, size_t m, fr_t* __restrict__ h) {
+    extern __shared__ uint4 lds[];
+    const size_t i = blockIdx.x;
+    chain_sponge(P, RK, lds, 9, ldg(init + 16), [&](size_t q) -> fr_t {
+        if (q == 4) return ldg(f + i);
+        if (q == 5) return f_next ? ldg(f_next + i / m) : fr_zero<PF>();
+        return ldg(init + q);
+    }, h + i);
 }
 #endif
 

@@ -254,3 +254,33 @@ def test_coset_ntt_with_merged_tables_equals_separate_tables_and_oracle(gpu_ctx,
     if host is not None:
         assert (outs[0].cpu().numpy().view(np.uint64) == oracle.ntt(field, host, coset=shift)).all()
     del outs, x, y; gpu_ctx.trim()
+
+
+@pytest.mark.parametrize("nodes,arity,last", [(1, 16, 16), (1, 16, 3), (37, 16, 16), (512, 16, 11), (257, 16, 16), (513, 16, 16), (200, 9, 2), (64, 12, 12)])
+def test_small_merkle_levels_five_wave_kernel_equals_oracle_and_one_wave_kernel(gpu_ctx, oracle, nodes, arity, last):
+    """Merkle levels of up to 256 nodes run one node per five-wave workgroup (poseidon_chain.hpp k_hash_ds_chain; above that one wave per node):
+    the oracle's hash_with_ds_dynamic on every node (ragged last node, one- and two-permutation inputs), and the one-wave kernel under option
+    "sponge_one_wave" on all of them."""
+    import numpy as np
+    p17 = gpu_ctx.poseidon_params_for_width(17)
+    ch = oracle.synth_column(900 + nodes, arity, 0, (nodes - 1) * arity + last)
+    got = gpu_ctx.hash_ds_level(p17, arity, 3, 1000, 42, ch)
+    assert got.shape[0] == nodes
+    fe = lambda x: oracle.from_u64(x)
+    for k in sorted({0, 1, nodes // 2, nodes - 2, nodes - 1} & set(range(nodes))):
+        kids = ch[arity * k: arity * k + arity]
+        ds = np.array([fe(arity), fe(3), fe(1000 + k), fe(42)])
+        assert (got[k] == oracle.hash_with_ds_dynamic(0, 17, ds, kids, kids.shape[0])).all(), k
+    try:
+        gpu_ctx._chk(gpu_ctx.lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", 1))
+        assert (gpu_ctx.hash_ds_level(p17, arity, 3, 1000, 42, ch) == got).all()
+    finally:
+        gpu_ctx._chk(gpu_ctx.lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", 0))
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (300, 4), (2048, 16), (2049, 16)])
+def test_small_leaf_layers_five_wave_kernel_equals_oracle(gpu_ctx, oracle, n, m):
+    """hash_leaf_pair over layers of up to 2048 leaves: one leaf per five-wave workgroup (k_leaf_pair_chain); oracle on every leaf, with and without f_next."""
+    f = oracle.synth_column(700 + n, 0, 0, n); fn = oracle.synth_column(700 + n, 1, 0, (n + m - 1) // m)
+    assert (gpu_ctx.leaf_pair_hash(f, fn, m) == oracle.leaf_pair_hash(f, fn, m)).all()
+    assert (gpu_ctx.leaf_pair_hash(f, None, 1) == oracle.leaf_pair_hash(f, None, 1)).all()
