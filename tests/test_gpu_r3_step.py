@@ -163,10 +163,10 @@ def test_handles_outlive_their_context(oracle):
     assert lib.stark_poseidon_params_free(p) == 0            # the last handle: the context is released here
 
 
-@pytest.mark.parametrize("k,n", [(0, 3), (1, 2), (15, 2), (16, 2), (17, 3), (127, 2), (128, 3), (129, 1), (1000, 5), (4096 + 7, 2)])
+@pytest.mark.parametrize("k,n", [(0, 3), (1, 2), (15, 2), (16, 2), (17, 3), (127, 2), (128, 3), (129, 1), (1000, 5), (4096 + 7, 2), (3, 512), (40, 513)])
 def test_five_wave_sponge_equals_oracle_and_one_wave_kernel(gpu_ctx, oracle, k, n):
-    """tr_hash_fields_tagged (crates/deep_ali/src/fri.rs:28-35) over n streams of k fields: from 128 fields on the library runs the three-wave
-    kernel (poseidon_chain.hpp: partial rounds unrolled, dependent chain in row form, helper waves), below that and with the option
+    """tr_hash_fields_tagged (crates/deep_ali/src/fri.rs:28-35) over n streams of k fields: up to 512 streams run the five-wave
+    kernel (poseidon_chain.hpp: partial rounds unrolled, dependent chain in row form, helper waves), more than that and the option
     "sponge_one_wave" the round-2 one-wave kernel.  Both equal the oracle at every length around the rate-16 block boundaries."""
     import numpy as np
     fields = oracle.synth_column(4242 + k, 3, 0, max(1, k * n))[:k * n]
