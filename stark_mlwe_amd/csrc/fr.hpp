@@ -81,6 +81,35 @@ template <class F> FR_HD bool fr_geq_p(const uint32_t* t) {
     return br == 0;
 }
 // conditional final subtraction: r = (t >= p || carry) ? t - p : t
+// Eight-word add / subtract with carry.  Device: explicit carry chains (__builtin_addc / __builtin_subc -> v_add_co_u32 / v_addc_co_u32, one
+// instruction per word).  Written with 64-bit intermediates the compiler zero-extends every word into a register pair and adds pairs
+// (v_mov + v_ashrrev + 2 x v_lshl_add_u64 per word: a quarter of the hot loops' non-MAC instructions in the Poseidon kernels were that).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class F> FR_HD void fr_cond_sub(uint32_t* t, uint32_t carry) {
+    uint32_t d[8]; unsigned c = 1;                       // t + ~P + 1: the carry out is 1 exactly when t >= P
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { unsigned co; d[i] = __builtin_addc(t[i], ~F::P(i), c, &co); c = co; }
+    const bool take = carry || c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = take ? d[i] : t[i];
+}
+template <class F> FR_HD fr_t fr_add(const fr_t& a, const fr_t& b) {
+    fr_t z; unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { unsigned co; z.v[i] = __builtin_addc(a.v[i], b.v[i], c, &co); c = co; }
+    fr_cond_sub<F>(z.v, c);
+    return z;
+}
+template <class F> FR_HD fr_t fr_sub(const fr_t& a, const fr_t& b) {
+    fr_t z; unsigned br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { unsigned bo; z.v[i] = __builtin_subc(a.v[i], b.v[i], br, &bo); br = bo; }
+    const uint32_t mask = br ? 0xffffffffu : 0u; unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { unsigned co; z.v[i] = __builtin_addc(z.v[i], F::P(i) & mask, c, &co); c = co; }
+    return z;
+}
+#else
 template <class F> FR_HD void fr_cond_sub(uint32_t* t, uint32_t carry) {
     uint32_t d[8]; uint64_t br = 0;
 #pragma unroll
@@ -105,6 +134,7 @@ template <class F> FR_HD fr_t fr_sub(const fr_t& a, const fr_t& b) {
     for (int i = 0; i < 8; ++i) { uint64_t s = (uint64_t)z.v[i] + (F::P(i) & mask) + c; z.v[i] = (uint32_t)s; c = s >> 32; }
     return z;
 }
+#endif
 template <class F> FR_HD fr_t fr_neg(const fr_t& a) { return fr_sub<F>(fr_zero<F>(), a); }
 
 // Montgomery product, word-serial CIOS over 32-bit limbs (portable C++: host build and reference for

@@ -91,7 +91,7 @@ FR_HD void fr_wide29_norm(fr_wide29& w) {
 // above 2^232).  For a sum of K products of operands below 2r the quotient is below (K/32 + 1) r.
 // MAC_POW2: a power-of-two limb of the modulus (Pallas: limb 8 = 2^22) is normally strength-reduced to a 64-bit shift plus a 64-bit
 // add (two full-rate instructions per digit) — right for the throughput kernels, whose multiplier pipe is the saturated resource
-// (measured: leaf kernel 3 % SLOWER with the MAC form).  On a lone wave every instruction costs one ~5-cycle issue slot, so the
+// (measured: leaf kernel 3 % SLOWER with the MAC form in round 2, 1.3 % slower again in round 3 with the multiplier in an SGPR).  On a lone wave every instruction costs one ~5-cycle issue slot, so the
 // latency kernels (poseidon_coop.hpp) hold the limb in a register as an opaque multiplier: ONE v_mad_u64_u32 per digit instead of two
 // instructions (sponge 145.6 -> 141.9 us per permutation).
 template <class F, bool MAC_POW2 = false> FR_HD void fr_wide29_mont(fr_wide29& w, uint32_t* l) {
@@ -108,7 +108,7 @@ template <class F, bool MAC_POW2 = false> FR_HD void fr_wide29_mont(fr_wide29& w
     for (int k = 0; k < 9; ++k) {
         const uint64_t t = w.c[k];
         const uint32_t m = (0u - (uint32_t)t) & FR_M29;            // t + m * r == 0 (mod 2^29) because r == 1 (mod 2^29)
-        w.c[k + 1] += (t + m) >> 29;
+        w.c[k + 1] += (t + FR_M29) >> 29;                          // == (t + m) >> 29, the multiple of 2^29 above t; adding the constant needs no zero-extended m
 #pragma unroll
         for (int j = 1; j < 9; ++j)
             if (fr_p29<F>(j) != 0) w.c[k + j] += (uint64_t)m * pj[j];
