@@ -30,7 +30,7 @@ template <class V> FR_HD void mfma_fold_rows(int64_t* col, const V& lo, const V&
                 const V& a = hh ? hi : lo;
                 const int64_t pair = (int64_t)a[4 * q + 2 * p] + (int64_t)a[4 * q + 2 * p + 1] * 256;
                 const int c = 32 * rt + 8 * q + 4 * hh + 2 * p, k = (8 * c) / 29, sh = 8 * c - 29 * k;
-                col[k] += pair << sh;
+                col[k] += pair * ((int64_t)1 << sh);      // pair may be negative: a product, not a shift of a signed value (undefined before C++20)
             }
 }
 // columns (signed, the total a non-negative integer) -> canonical field element: signed carry pass, Montgomery step by 2^261

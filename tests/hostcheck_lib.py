@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "stark_mlwe_amd", "libstark_mlwe_hostcheck.so")
+PATH = os.environ.get("STARK_HOSTCHECK_LIB") or os.path.join(ROOT, "stark_mlwe_amd", "libstark_mlwe_hostcheck.so")    # the override: a sanitizer build (tools/host_sanitize.sh)
 vp = C.c_void_p
 
 
