@@ -166,6 +166,9 @@ def _trace_worker(rank, world, port, log_n, q):
         for l in range(4):
             r = np.zeros(4, np.uint64); ctx._chk(lib.stark_fri_layer_root(st, l, _ptr(r)))
             ok = ok and bool((np.asarray(roots[l]).view(np.uint64).reshape(4) == r).all())
+        gold = bench.golden_step_roots(log_n, 0x5EED0000 + log_n)      # the CPU oracle's roots for this very trace, where a golden exists (2^20 rows)
+        if gold is not None:
+            ok = ok and bench.roots_hex(roots) == gold
         ctx._chk(lib.stark_fri_state_free(st)); ctx.close()
         q.put((rank, ok))
     except Exception as ex:      # noqa: BLE001 — report instead of leaving the parent waiting
@@ -175,10 +178,11 @@ def _trace_worker(rank, world, port, log_n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("log_n", [14, 18])
+@pytest.mark.parametrize("log_n", [14, 18, 20])
 def test_sharded_trace_two_ranks_one_gpu(log_n):
     """The N > 1 bench step on 2 ranks sharing the GPU (gloo exchange): sharded LDE (six-step NTTs with real rank offsets, pack
-    kernels), shard merge and sharded commit give the roots of the one-GPU step over the whole trace."""
+    kernels), shard merge and sharded commit give the roots of the one-GPU step over the whole trace — and at 2^20 rows (the bench's
+    trace) the roots of the CPU oracle (tests/golden/step_roots_k20.json)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30300 + (os.getpid() % 1000) + log_n
