@@ -78,6 +78,8 @@ int32_t stark_ctx_trim(stark_ctx_t* ctx);     /* also drops the NTT plans (direc
  *   "ntt_direct_max_log" (default 24: one-product twiddle tables up to 2^24 points; 0 = always the two-level lookup),
  *   "ntt_merged_coset" (default 1: a coset transform's pre-scale is folded into its first pass's twiddle table; 0 = separate tables),
  *   "ntt_log_tile" (8..12, default 11; -1 restores the default), "ntt_min_waves" (2 | 4), "poseidon_lane_only" (0 | 1).
+ *   "sponge_one_wave" (0 | 1: long serial sponges, small Merkle levels / leaf layers and short transcript hashes on the one-wave / wave-pair kernels
+ *   instead of the five-wave latency kernel; comparison), "sponge_debug" (timing experiments on the five-wave kernel; digests are WRONG when set).
  * Changing an option synchronises the stream and drops the cached NTT plans. */
 int32_t stark_ctx_set_option(stark_ctx_t* ctx, const char* key, int64_t value);
 size_t  stark_ctx_cached_bytes(stark_ctx_t* ctx);

@@ -135,6 +135,20 @@ template <class F> FR_HD fr_t fr29_pack_reduce(const uint32_t* l) {
     for (int i = 0; i < 8; ++i) z.v[i] = t[i];
     return z;
 }
+// The same WITHOUT the final conditional subtract: the eight words of the quotient (below 1.1 r for the short sums it is used on), not canonical.
+template <class F> FR_HD fr_t fr_wide29_reduce_lazy(fr_wide29& w) {
+    uint32_t l[9]; fr_wide29_mont<F>(w, l);
+    fr_t z;
+#pragma unroll
+    for (int wd = 0; wd < 8; ++wd) {
+        const int lo = 32 * wd, i = lo / 29, s = lo - 29 * i;
+        uint32_t v = l[i] >> s;
+        if (i + 1 < 9) v |= l[i + 1] << (29 - s);
+        if (29 - s + 29 < 32 && i + 2 < 9) v |= l[i + 2] << (58 - s);
+        z.v[wd] = v;
+    }
+    return z;
+}
 // Montgomery reduction by R' = 2^261 and return to eight 32-bit limbs, fully reduced.
 template <class F, bool MAC_POW2 = false> FR_HD fr_t fr_wide29_reduce(fr_wide29& w) {
     uint32_t l[9]; fr_wide29_mont<F, MAC_POW2>(w, l);

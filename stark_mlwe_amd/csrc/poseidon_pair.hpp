@@ -184,7 +184,10 @@ __device__ __forceinline__ fr_t pair_lane_update(const uint32_t* sp, int j, cons
     fr_wide29 u; fr_wide29_zero(u);
     fr_wide29_mac(u, c29(sp, 0 * W + T - 1 + j), x0); fr_wide29_mac(u, c29(sp, 1 * W + T - 1 + j), x1);
     fr_wide29_mac(u, c29(sp, 2 * W + T - 1 + j), x2); fr_wide29_mac(u, c29(sp, 3 * W + T - 1 + j), x3);
-    return fr_add<PF>(base, fr_wide29_reduce<PF>(u));
+    // The lanes are NOT canonical between the blocks: the Montgomery quotient (below 1.1 r) is added as it is and r subtracted once, so a lane grows by
+    // at most 0.1 r per block (below 2.7 r after the 16 blocks: eight words hold it); its consumers unpack and multiply (quotient bounds of fr29.hpp hold
+    // for operands below 4 r), and the next full round's S-box returns canonical values.
+    return fr_add<PF>(base, fr_wide29_reduce_lazy<PF>(u));
 }
 
 // One permutation by the wave pair.  Precondition: state consistent (a barrier since the last write).
