@@ -192,7 +192,30 @@ __global__ void __launch_bounds__(MINW > 2 ? 256 : 512, MINW) k_ntt_strided(NttP
     for (uint64_t t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
         const TileJob J = job(t);
         int head;
-        if (PRE) {
+        if (PRE && A.nz_points && A.log_b >= 3 && A.nz_points <= (uint32_t)(B >> 3)) {
+            // Zero-padded input (LDE) whose non-zero points p < B/8 are the FIRST point of every head group: the three head stages pair a value with zeros,
+            // (a, 0) -> (a, a), so the scaled point goes to the eight rows of its group as it is — no zeros written and read back, no head arithmetic.
+            const int nzc = (int)A.nz_points << A.log_c;
+            for (int idx = threadIdx.x; idx < nzc; idx += blockDim.x) {
+                const int c = idx & (C - 1), p = idx >> A.log_c;
+                const uint64_t g = J.base + (uint64_t)p * A.stride + c;
+                const fr_t m = A.pre_small ? ldg(A.pre_small + p) : A.pre_direct ? ldg(A.pre_direct + (g & ((1ull << A.log_n) - 1)))
+                                            : pow_lookup<F>(A.pre, A.pre_row_stride ? (uint64_t)p * A.pre_row_stride + A.rest0 + (J.tile << A.log_c) + c : g);
+                const fr29_t x = fr29_mul_mont<F>(fr29_unpack(m), fr29_unpack(ldg(src + g)));
+                const int row0 = (int)(bitrev((uint32_t)p, A.log_b - 3) << 3);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t29_st(L.data, ((row0 + k) << A.log_c) + c, x);
+            }
+            for (int idx = threadIdx.x + nzc; idx < ((B >> 3) << A.log_c); idx += blockDim.x) {      // groups whose first point is zero too (nz_points < B/8)
+                const int c = idx & (C - 1), p = idx >> A.log_c; fr29_t z;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) z.l[i] = 0;
+                const int row0 = (int)(bitrev((uint32_t)p, A.log_b - 3) << 3);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t29_st(L.data, ((row0 + k) << A.log_c) + c, z);
+            }
+            head = 3;
+        } else if (PRE) {
             for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
                 const int c = idx & (C - 1), p = idx >> A.log_c;
                 fr29_t x;
