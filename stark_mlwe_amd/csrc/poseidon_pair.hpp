@@ -30,8 +30,13 @@
 namespace stark {
 
 template <int T> struct PairCfg {
-    static constexpr int NXD = T == 17 ? 3 : 2;        // X's share of the lanes in the per-round dot products: lanes 1..NXD (X's sums stay
-                                                       // <= 7 terms: no carry pass in the S-box chain; Y takes the other lanes)
+#ifndef STARK_NXD17
+#define STARK_NXD17 5
+#endif
+    // X's share of the lanes in the per-round dot products: lanes 1..NXD, Y the other T - 1 - NXD.  Between two barriers X runs the S-box (three products),
+    // a_q x_q, up to three gamma terms and its NXD lane terms, Y its lane terms: NXD = 5 balances the two for t = 17 (measured, 2^22 leaves: 61.0 ms at 3,
+    // 60.2 at 4, 59.3 at 5, 60.5 at 6); from eight terms on X's sum takes one carry pass in between (rounds 2 and 3 of a block).
+    static constexpr int NXD = T == 17 ? STARK_NXD17 : 2;
 #ifndef STARK_NXU17
 #define STARK_NXU17 8
 #endif
@@ -224,7 +229,7 @@ __device__ __forceinline__ fr_t pair_permute(const PairState& s, const PoseidonD
                 if (q > 0) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 0), fr29_unpack(s.ld(Cfg::xslot(0)))); \
                 if (q > 1) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 1), fr29_unpack(s.ld(Cfg::xslot(1)))); \
                 if (q > 2) fr_wide29_mac(acc, c29(g, q * (q - 1) / 2 + 2), fr29_unpack(s.ld(Cfg::xslot(2)))); \
-                static_assert(1 + 3 + NXD <= fr29_max_terms<PF>(), "terms between carry passes (fr29.hpp)");   \
+                if (1 + q + NXD > fr29_max_terms<PF>()) fr_wide29_norm(acc);   /* terms between carry passes (fr29.hpp); with NXD = 3 never */ \
                 _Pragma("unroll") for (int j = 0; j < NXD; ++j) fr_wide29_mac(acc, c29(sp, q * W + 1 + j), fr29_unpack(keep[j])); \
                 const fr_t part = fr_wide29_reduce<PF>(acc);                                          \
                 __syncthreads();                                       /* barrier_q: Dy_q is posted */ \
