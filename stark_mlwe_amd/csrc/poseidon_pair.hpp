@@ -12,8 +12,8 @@
 //                   - t = 9: as in-place L*(U*x) on the VALU, X taking the even rows and Y the odd rows of each step (rows
 //                     2k/2k+1 read only slots >= 2k, so a single barrier between the step's reads and its two writes keeps it race-free);
 //   * partial rounds, in blocks of 4 (see permute_core in poseidon_dev.hpp for the algebra):
-//       phase 1  X runs the S-box chain: x_q, then a_q x_q + sum_{p<q} gamma x_p + its quarter of the
-//                lane dot product from registers; Y computes the other three quarters of every round's
+//       phase 1  X runs the S-box chain: x_q, then a_q x_q + sum_{p<q} gamma x_p + its share (lanes 1..NXD) of the
+//                lane dot product from registers; Y computes the other lanes' part of every round's
 //                dot product from the block-start state and posts it in an LDS mailbox (one barrier per round);
 //       phase 2  both waves bring their half of the lanes up to date, s_j += sum_p w_{p,j} x_p (one
 //                reduction per lane), X from registers, Y from the x mailboxes.
@@ -35,7 +35,8 @@ template <int T> struct PairCfg {
 #endif
     // X's share of the lanes in the per-round dot products: lanes 1..NXD, Y the other T - 1 - NXD.  Between two barriers X runs the S-box (three products),
     // a_q x_q, up to three gamma terms and its NXD lane terms, Y its lane terms: NXD = 5 balances the two for t = 17 (measured, 2^22 leaves: 61.0 ms at 3,
-    // 60.2 at 4, 59.3 at 5, 60.5 at 6); from eight terms on X's sum takes one carry pass in between (rounds 2 and 3 of a block).
+    // 60.2 at 4, 59.3 at 5, 60.5 at 6; a share that shrinks with the round as X's gamma terms grow — 6,5,5,4 / 6,6,5,4 / 7,6,5,4 — 61.4 / 61.2 / 60.7);
+    // from eight terms on X's sum takes one carry pass in between (rounds 2 and 3 of a block).
     static constexpr int NXD = T == 17 ? STARK_NXD17 : 2;
 #ifndef STARK_NXU17
 #define STARK_NXU17 8
