@@ -294,6 +294,7 @@ def main():
         sections["serial_sponge"] = sponge_section(ctx, torch, dev)
         sections["reference_bench"] = reference_bench(ctx, np, args.csv, world)
         sections["reference_bench_presets"] = preset_bench(ctx, np, torch, dev, args.csv, world)
+        sections["reference_bench_sumcheck"] = sumcheck_bench(ctx, np, torch, dev)
 
     if rank == 0:
         traffic = None
@@ -394,6 +395,33 @@ PRESETS = [("mod16", [16, 16, 16, 16]), ("uni32x3", [32, 32, 32]), ("uni64x2x8",
 PUBLISHED_PRESET_MS = {("mod16", 16): (55906.8, 240.5), ("uni32x3", 15): (27146.9, 162.1), ("uni32x3", 16): (54165.2, 195.1), ("uni64x2x8", 15): (26999.7, 135.5),
                        ("uni64x2x8", 16): (53552.6, 166.4), ("hi64_32_8", 14): (13454.9, 130.8), ("hi64_32_8", 15): (27069.2, 150.0), ("hi64_32_8", 16): (53520.7, 183.3),
                        ("hi32_32_16", 14): (13647.6, 148.4), ("hi32_32_16", 15): (27093.2, 169.0), ("hi32_32_16", 16): (54904.8, 196.2)}
+
+
+# The reference's sum-check benches (`e2e_plain` prove / verify at k = 12, 14, 16; `e2e_mf` at k = 12, 14, two queries per round;
+# Criterion means, Apple arm64, 1 thread) — N4, the second consumer of the Merkle kernels (crates/channel/src/lib.rs:1045-1240).
+PUBLISHED_SUMCHECK_MS = {("plain", 12): (148.3, 4.05), ("plain", 14): (585.9, 4.59), ("plain", 16): (2363.3, 5.13), ("mf", 12): (323.4, 25.8), ("mf", 14): (1207.0, 34.1)}
+
+
+def sumcheck_bench(ctx, np, torch, dev):
+    """prove_plain / prove_mf / verify_* through the C-ABI on a synthetic 2^k-entry witness (host buffers, as the reference's API takes them)."""
+    lib = ctx.lib; rows = []
+    for (variant, k), (pub_p, pub_v) in sorted(PUBLISHED_SUMCHECK_MS.items()):
+        wdev = torch.empty((1 << k, 4), dtype=torch.int64, device=dev)
+        ctx._chk(lib.stark_synth_column_dev(ctx.h, 0x5C0000 + k, 0, 0, 1 << k, C.c_void_p(wdev.data_ptr())))
+        w = wdev.cpu().numpy().view(np.uint64)
+        prove = (lambda: ctx.prove_plain(k, 2025, w)) if variant == "plain" else (lambda: ctx.prove_mf(k, 2025, 2, w))
+        verify = (lambda pr: ctx.verify_plain(k, 2025, pr)) if variant == "plain" else (lambda pr: ctx.verify_mf(k, 2025, 2, pr))
+        prove()                                                        # warm: parameters, plans
+        best_p, best_v, ok, proof = 1e9, 1e9, True, b""
+        for _ in range(3):
+            t0 = time.perf_counter(); proof = prove(); best_p = min(best_p, time.perf_counter() - t0)
+            t0 = time.perf_counter(); ok = verify(proof) and ok; best_v = min(best_v, time.perf_counter() - t0)
+        bad = bytearray(proof); bad[len(bad) // 2] ^= 1
+        rows.append({"variant": variant, "k": k, "prove_ms": best_p * 1e3, "verify_ms": best_v * 1e3, "proof_bytes": len(proof), "verified": bool(ok),
+                     "tampered_rejected": not verify(bytes(bad)), "published_prove_ms": pub_p, "published_verify_ms": pub_v})
+    return {"rows": rows, "all_verified": all(r["verified"] and r["tampered_rejected"] for r in rows),
+            "note": "synthetic witness from host memory (upload included); published_* = the reference authors' Criterion means (Apple arm64, 1 thread; SURVEY.md §6(b)); "
+                    "proof bytes are compared with the oracle's in tests/test_gpu_r2_sumcheck.py (parity unpinned: the reference holds no vectors for this path)"}
 
 
 def preset_bench(ctx, np, torch, dev, csv_path, gpus):

@@ -375,8 +375,11 @@ __device__ __forceinline__ void chain_partial_rounds(uint32_t& sr, const Poseido
 // into a state whose capacity element starts as `cap`, the lazy duplex of transcript/src/lib.rs:79-88 (permute only before absorbing more, once at
 // the end) — which is also hash_with_ds_dynamic's eager sponge over ds || children || 1 (crates/poseidon/src/lib.rs:219-312: the same permutations at
 // the same points, cap = 0).  Element 0 of the final state goes to *out_slot.
+// state_in != nullptr: the sponge RESUMES from 17 stored elements (the streaming transcript of sumcheck_impl.hpp; cap is ignored); final_permute = false leaves
+// the last block absorbed but not permuted; state_out != nullptr receives the 17 elements of the final state (canonical).
 template <class Elem>
-__device__ __forceinline__ void chain_sponge(const PoseidonDev& P, const row::Consts& RK, uint4* lds, size_t total, const fr_t& cap, Elem elem, fr_t* out_slot) {
+__device__ __forceinline__ void chain_sponge_ex(const PoseidonDev& P, const row::Consts& RK, uint4* lds, size_t total, const fr_t& cap, Elem elem, fr_t* out_slot,
+                                                const fr_t* state_in, bool final_permute, fr_t* state_out) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     CoopLds L = coop_setup<17>(lds, P);                                  // ends with a workgroup barrier
     ChainLds C;
@@ -392,8 +395,9 @@ __device__ __forceinline__ void chain_sponge(const PoseidonDev& P, const row::Co
     __syncthreads();
     const ChainPre pre = chain_preload(P, wave, lane);
     const uint32_t cidx = lane & 15; const int e = 4 * wave + (lane >> 4); const bool valid = e < 17;
-    // the state in row form; element 16 starts as the capacity constant
-    if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(cap); for (int i = 0; i < 9; ++i) C.sfin[16 * 16 + i] = u.l[i]; }
+    // the state in row form; element 16 starts as the capacity constant (or all 17 elements come from state_in)
+    if (state_in) { if (threadIdx.x < 17) { const fr29_t u = fr29_unpack(ldg(state_in + threadIdx.x)); for (int i = 0; i < 9; ++i) C.sfin[threadIdx.x * 16 + i] = u.l[i]; } }
+    else if (threadIdx.x == 0) { const fr29_t u = fr29_unpack(cap); for (int i = 0; i < 9; ++i) C.sfin[16 * 16 + i] = u.l[i]; }
     __syncthreads();
     uint32_t sr = valid ? C.sfin[e * 16 + cidx] : 0u;
     auto fetch = [&](size_t base) -> fr_t {
@@ -417,15 +421,20 @@ __device__ __forceinline__ void chain_sponge(const PoseidonDev& P, const row::Co
         __syncthreads();
         if (e < 16) sr += C.in[e * 16 + cidx];                            // absorbed lazily: limbs stay below 2^31
     }
-    permute(cbase);
-    if (wave == 0 && lane < 16) C.sfin[cidx] = sr;                        // element 0, lazy
+    if (final_permute) permute(cbase);
+    if (valid) C.sfin[e * 16 + cidx] = sr;                                // the state, lazy (pad lanes of a row: zeros)
     __syncthreads();
-    if (threadIdx.x == 0) {
-        fr29_t v; for (int i = 0; i < 9; ++i) v.l[i] = C.sfin[i];
+    if (threadIdx.x < 17 && (state_out || threadIdx.x == 0)) {
+        fr29_t v; for (int i = 0; i < 9; ++i) v.l[i] = C.sfin[threadIdx.x * 16 + i];
         fr_t s = chain_canon(v);
         if (lds_vload(C.flag + 3)) s = fr_zero<PF>();                    // a timed-out wait (never seen) must not pass for a digest
-        stg(out_slot, s);
+        if (state_out) stg(state_out + threadIdx.x, s);
+        if (threadIdx.x == 0 && out_slot) stg(out_slot, s);
     }
+}
+template <class Elem>
+__device__ __forceinline__ void chain_sponge(const PoseidonDev& P, const row::Consts& RK, uint4* lds, size_t total, const fr_t& cap, Elem elem, fr_t* out_slot) {
+    chain_sponge_ex(P, RK, lds, total, cap, elem, out_slot, nullptr, true, nullptr);
 }
 
 // The column sponges of build_f0 (and any other long tr_hash_fields_tagged chain): one workgroup of five waves per chain.  Same job description as

@@ -77,6 +77,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     if (lane == 0) { *pos_io = pos; if (out) stg(out, s); }
 }
 
+// The same on the five waves of poseidon_chain.hpp (72 us per permutation instead of 142 us): the stored cursor becomes `pos` leading no-op elements of
+// the stream, so that the block boundaries — and with them the lazy permutations — fall where k_tr_stream puts them.
+__global__ void __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) k_tr_stream_chain(PoseidonDev P, row::Consts RK, fr_t* __restrict__ state, uint32_t* __restrict__ pos_io,
+                                                                                                  const fr_t* __restrict__ fields, uint64_t n, int finish, fr_t* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    const uint32_t pos = *pos_io;                                                           // every thread reads it before thread 0 writes it back (barriers in between)
+    const size_t total = (size_t)pos + n;
+    chain_sponge_ex(P, RK, lds, total, fr_zero<PF>(), [&](size_t q) -> fr_t { return q < pos ? fr_zero<PF>() : ldg(fields + (q - pos)); },
+                    finish ? out : (fr_t*)nullptr, state, finish != 0, state);
+    if (threadIdx.x == 0) *pos_io = finish ? 0u : (total ? (uint32_t)(total - 16 * ((total - 1) / 16)) : 0u);
+}
+
 // ---- device-resident transcript -----------------------------------------------------------------------------------------
 struct DevTranscript {
     stark_ctx* ctx; DevBuf state, posb, out; std::vector<fr_t> pending; stark_params* tp = nullptr;
@@ -100,6 +112,10 @@ struct DevTranscript {
     int32_t run(bool finish, fr_t* result) {
         DevBuf f; const size_t n = pending.size();
         if (n) { STARK_HIP(ctx, f.alloc(ctx, n * sizeof(fr_t))); STARK_HIP(ctx, hipMemcpyAsync(f.p, pending.data(), n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream)); }
+        if (use_chain(ctx, tp->dev, 1, 1)) {
+            (void)hipFuncSetAttribute((const void*)k_tr_stream_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+            hipLaunchKernelGGL(k_tr_stream_chain, dim3(1), dim3(320), chain_lds_bytes(), ctx->stream, tp->dev, row_consts_of(ctx), state.fr(), (uint32_t*)posb.p, (const fr_t*)f.fr(), (uint64_t)n, finish ? 1 : 0, finish ? out.fr() : (fr_t*)nullptr);
+        } else
         hipLaunchKernelGGL(k_tr_stream, dim3(1), dim3(64), coop_lds_bytes(17), ctx->stream, tp->dev, state.fr(), (uint32_t*)posb.p, (const fr_t*)f.fr(), (uint64_t)n, finish ? 1 : 0, finish ? out.fr() : (fr_t*)nullptr);
         STARK_HIP(ctx, hipGetLastError());
         if (finish && result) STARK_HIP(ctx, hipMemcpyAsync(result, out.p, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
