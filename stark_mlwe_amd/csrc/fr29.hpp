@@ -91,7 +91,8 @@ FR_HD void fr_wide29_norm(fr_wide29& w) {
 // above 2^232).  For a sum of K products of operands below 2r the quotient is below (K/32 + 1) r.
 // MAC_POW2: a power-of-two limb of the modulus (Pallas: limb 8 = 2^22) is normally strength-reduced to a 64-bit shift plus a 64-bit
 // add (two full-rate instructions per digit) — right for the throughput kernels, whose multiplier pipe is the saturated resource
-// (measured: leaf kernel 3 % SLOWER with the MAC form in round 2, 1.3 % slower again in round 3 with the multiplier in an SGPR).  On a lone wave every instruction costs one ~5-cycle issue slot, so the
+// (measured: leaf kernel 3 % SLOWER with the MAC form in round 2, 1.3 % slower again in round 3 with the multiplier in an SGPR); the NTT butterflies,
+// whose instruction mix has fewer MACs per instruction, take the MAC form too (LDE 2^20 -> 2^23 -2.3 %, 2^23 coset NTT -1.5 %).  On a lone wave every instruction costs one ~5-cycle issue slot, so the
 // latency kernels (poseidon_coop.hpp) hold the limb in a register as an opaque multiplier: ONE v_mad_u64_u32 per digit instead of two
 // instructions (sponge 145.6 -> 141.9 us per permutation).
 template <class F, bool MAC_POW2 = false> FR_HD void fr_wide29_mont(fr_wide29& w, uint32_t* l) {
@@ -216,7 +217,7 @@ template <class F> FR_HD void fr29_partial_reduce(fr29_t& x) {
 // Growth per stage: limbs of a by at most 2^29 (sum) / 2^30 (difference), the value by at most 4r.
 template <class F> FR_HD void ntt29_butterfly(fr29_t& a, fr29_t& b, const fr29_t& tw, const uint32_t* __restrict__ D, bool norm) {
     if (norm) { fr29_norm(a); fr29_norm(b); }
-    const fr29_t p = fr29_mul_mont<F>(tw, b);
+    const fr29_t p = fr29_mul_mont<F, true>(tw, b);
 #pragma unroll
     for (int k = 0; k < 9; ++k) { const uint32_t av = a.l[k]; a.l[k] = av + p.l[k]; b.l[k] = av + D[k] - p.l[k]; }
 }

@@ -166,7 +166,7 @@ __device__ __forceinline__ void last_stage(const NttPassArgs& A, const Tile29& D
 template <class F>
 __device__ __forceinline__ fr_t finish29(fr29_t y, const fr_t& mult, bool norm) {
     if (norm) fr29_norm(y);
-    const fr29_t r = fr29_mul_mont<F>(fr29_unpack(mult), y);
+    const fr29_t r = fr29_mul_mont<F, true>(fr29_unpack(mult), y);
     return fr29_pack_reduce<F>(r.l);
 }
 // an output that takes no factor: reduced without a product
