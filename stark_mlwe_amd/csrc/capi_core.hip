@@ -24,7 +24,7 @@ static inline bool use_pair(const stark_ctx* ctx, int t) { return !ctx->opt_pose
 // to 256 nodes (two permutations: 155 us against 290 us on one wave each; equal from 512 nodes on), leaf layers of up to 2048 leaves (one permutation:
 // 80 us per 256 leaves against the 0.77 ms a launch of the wave-pair throughput kernel takes whatever its size).  tools/latency_timing.py;
 // option "sponge_one_wave" keeps them on the one-wave / wave-pair kernels (comparison).
-constexpr size_t kChainMaxNodes = 256, kChainMaxLeaves = 2048;
+constexpr size_t kChainMaxNodes = 256, kChainMaxLeaves = 2048, kCoopMaxLeaves = 4096, kCoopMaxNodes = 4096;      // leaf layers above kChainMaxLeaves: one wave per leaf up to kCoopMaxLeaves
 static inline bool use_chain(const stark_ctx* ctx, const PoseidonDev& d, size_t n, size_t n_max) {
     return !ctx->opt_poseidon_lane_only && !ctx->opt_sponge_one_wave && d.t == 17 && d.rf == 8 && d.rp == 64 && d.chain_a && n <= n_max;
 }
@@ -494,7 +494,7 @@ static int32_t launch_hash_ds(stark_ctx_t* ctx, hipStream_t st, stark_params_t* 
         hipLaunchKernelGGL(k_hash_ds_chain, dim3((unsigned)J.n_out), dim3(320), chain_lds_bytes(), st, p->dev, J, row_consts_of(ctx), in0, in1, out);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
-    if (use_pair(ctx, p->dev.t) && J.n_out <= 8192) {
+    if (use_pair(ctx, p->dev.t) && J.n_out <= kCoopMaxNodes) {
         // small level: one wave per node (latency form); a batch of 64 nodes per wave pair only pays off above that
         if (p->dev.t == 17) hipLaunchKernelGGL(k_hash_ds_coop<17>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(17), st, p->dev, J, in0, in1, out);
         else hipLaunchKernelGGL(k_hash_ds_coop<9>, dim3((unsigned)J.n_out), dim3(64), coop_lds_bytes(9), st, p->dev, J, in0, in1, out);
@@ -557,6 +557,10 @@ int32_t leaf_pair_hash_on(stark_ctx* ctx, hipStream_t st, const fr_t* f, const f
     fr_t* init = nullptr; STARK_TRY(ctx_leaf_init(ctx, &init));
     if (use_chain(ctx, tp->dev, n, kChainMaxLeaves)) {
         hipLaunchKernelGGL(k_leaf_pair_chain, dim3((unsigned)n), dim3(320), chain_lds_bytes(), st, tp->dev, row_consts_of(ctx), (const fr_t*)init, f, f_next, m, h);
+        STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
+    }
+    if (use_pair(ctx, 17) && !ctx->opt_sponge_one_wave && n <= kCoopMaxLeaves) {
+        hipLaunchKernelGGL(k_leaf_pair_coop, dim3((unsigned)n), dim3(64), coop_lds_bytes(17), st, tp->dev, (const fr_t*)init, f, f_next, m, h);
         STARK_HIP(ctx, hipGetLastError()); return STARK_OK;
     }
     if (use_pair(ctx, 17)) {

@@ -268,6 +268,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     if (lane == 0) stg(out + i, s);
 }
 
+// hash_leaf_pair (fri.rs:38-44), one wave per leaf: for layers too long for the five-wave kernel's one workgroup per CU and too short to fill the wave-pair
+// throughput kernel, whose launch takes 0.77 ms whatever its size (2049 .. 8192 leaves).  init = the 17-element template of capi_core.hip ctx_leaf_init.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_leaf_pair_coop(PoseidonDev P, const fr_t* __restrict__ init, const fr_t* __restrict__ f,
+                                                                                                 const fr_t* __restrict__ f_next, size_t m, fr_t* __restrict__ h) {
+    extern __shared__ uint4 lds[];
+    CoopLds L = coop_setup<17>(lds, P);
+    const int lane = threadIdx.x; const size_t i = blockIdx.x;
+    fr_t s = fr_zero<PF>();
+    if (lane < 17) s = lane == 4 ? ldg(f + i) : (lane == 5 ? (f_next ? ldg(f_next + i / m) : fr_zero<PF>()) : ldg(init + lane));
+    s = coop_permute<17>(s, P, L, lane);
+    if (lane == 0) stg(h + i, s);
+}
+
 // Up to 4 independent long sponges in ONE launch (one block each): the four column chains of build_f0.
 // With `batch` set, block b hashes column b & 3 of trace b >> 2 (stark_deep_fri_prove_batch_dev: the 4 * B chains of B independent traces
 // in one launch — each is serial, together they fill the chip); its fields pointer comes from the device array batch[b].

@@ -278,9 +278,10 @@ def test_small_merkle_levels_five_wave_kernel_equals_oracle_and_one_wave_kernel(
         gpu_ctx._chk(gpu_ctx.lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", 0))
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (300, 4), (2048, 16), (2049, 16)])
+@pytest.mark.parametrize("n,m", [(1, 1), (300, 4), (2048, 16), (2049, 16), (8192, 16), (8193, 8)])
 def test_small_leaf_layers_five_wave_kernel_equals_oracle(gpu_ctx, oracle, n, m):
-    """hash_leaf_pair over layers of up to 2048 leaves: one leaf per five-wave workgroup (k_leaf_pair_chain); oracle on every leaf, with and without f_next."""
+    """hash_leaf_pair over layers of up to 2048 leaves: one leaf per five-wave workgroup (k_leaf_pair_chain), up to 8192 one wave per leaf (k_leaf_pair_coop),
+    above that the wave-pair kernel; oracle on every leaf, with and without f_next."""
     f = oracle.synth_column(700 + n, 0, 0, n); fn = oracle.synth_column(700 + n, 1, 0, (n + m - 1) // m)
     assert (gpu_ctx.leaf_pair_hash(f, fn, m) == oracle.leaf_pair_hash(f, fn, m)).all()
     assert (gpu_ctx.leaf_pair_hash(f, None, 1) == oracle.leaf_pair_hash(f, None, 1)).all()

@@ -15,7 +15,7 @@ def timed(fn, reps=20):
 p17 = ctx.poseidon_params_for_width(17)
 for one_wave in (0, 1):
     ctx.set_option("sponge_one_wave", one_wave)
-    for n in (1, 16, 256, 512, 2048):
+    for n in (1, 16, 256, 512, 2048, 4096, 8192):
         f = torch.empty((n * 16, 4), dtype=torch.int64, device=dev); out = torch.empty((n, 4), dtype=torch.int64, device=dev)
         ctx._chk(lib.stark_synth_column_dev(ctx.h, 1, 0, 0, n * 16, P(f)))
         lvl = timed(lambda: ctx._chk(lib.stark_poseidon_hash_ds_batch_dev(ctx.h, p17.h, 16, 0, 0, 0, P(f), n * 16, P(out))))
