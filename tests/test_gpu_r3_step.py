@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-@pytest.mark.parametrize("k", [10, 20, 21])
+@pytest.mark.parametrize("k", [10, 20, 21, 22])
 def test_bench_step_roots_match_oracle_golden(gpu_ctx, k):
     """Exactly `bench.py`'s N = 1 step (`bench.make_single_gpu_step`: LDE of the four synthetic columns 2^k -> 2^(k+3) on the coset
     5*<w>, DEEP-ALI merge at z = 0xC0FFEE, fri_build_transcript [16,16,8] — crates/deep_ali/src/lib.rs:48-105,
-    crates/deep_ali/src/fri.rs:231-312): the four layer roots equal the oracle's, at 2^10 rows, at the bench size 2^20 rows x 8, and at 2^21 rows (the trace of the N = 2 bench)."""
+    crates/deep_ali/src/fri.rs:231-312): the four layer roots equal the oracle's, at 2^10 rows, at the bench size 2^20 rows x 8, and at 2^21 / 2^22 rows (the traces of the N = 2 and N = 4 bench)."""
     import torch
     import bench
     path = os.path.join(GOLD, f"step_roots_k{k}.json")
