@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--steps-only", action="store_true", help="only the timed steps and the headline fields (for rocprofv3 kernel stats)")
     ap.add_argument("--e2e-log", type=int, default=20, help="log2 rows of the end-to-end deep_fri_prove section (0 disables)")
     ap.add_argument("--synth-seed", type=lambda x: int(x, 0), default=None, help="seed of the synthetic trace (default 0x5EED0000 + log-trace); lets a 1-GPU run reproduce the trace of an N-GPU run")
+    ap.add_argument("--save-roots", default=None, help="write the step's roots (with the parameters that define the step) to this JSON file: a ONE-GPU run of a trace size that has no oracle golden, kept under tests/golden/step_roots_k<K>_one_gpu.json for the N > 1 runs of the same trace to compare with")
     ap.add_argument("--csv", default=None, help="also write the reference's benchmarkdata.csv schema (end_to_end.rs:42-44) for the reference-input proves")
     args = ap.parse_args()
 
@@ -231,6 +232,21 @@ def main():
     gold = golden_step_roots(log_total, seed)      # N > 1: the sharded step commits to the same 2^log_total-row trace as one GPU would (same roots)
     # True / False against the committed oracle golden of exactly this step; null when no golden exists for this size, seed or N
     out["roots_match_golden"] = None if gold is None else (out["roots"] == gold)
+    # product against product, where the CPU oracle is out of reach (2^23 rows = the N = 8 trace: about 6 h of the build container): the roots a ONE-GPU run
+    # of this very trace committed to (tests/golden/step_roots_k<K>_one_gpu.json, written by --save-roots); null when there is none or N = 1
+    one = None
+    if world > 1:
+        pth = os.path.join(ROOT, "tests", "golden", f"step_roots_k{log_total}_one_gpu.json")
+        if os.path.exists(pth):
+            g1 = json.load(open(pth))
+            if g1.get("synth_seed") == seed and g1.get("schedule") == SCHEDULE and g1.get("seed_z") == SEED_Z and g1.get("log_blowup") == LOG_BLOWUP and g1.get("coset") == STEP_COSET and g1.get("z") == STEP_Z:
+                one = out["roots"] == g1["roots"]
+    out["roots_match_one_gpu_run"] = one
+    if args.save_roots and rank == 0 and world == 1:
+        with open(args.save_roots, "w") as f:
+            json.dump({"log_trace": log_total, "log_blowup": LOG_BLOWUP, "schedule": SCHEDULE, "seed_z": SEED_Z, "synth_seed": seed, "coset": STEP_COSET, "z": STEP_Z,
+                       "roots": out["roots"], "generator": "bench.py --save-roots on ONE MI355X (the product, not the oracle)"}, f, indent=1)
+            f.write("\n")
     if args.steps_only:
         if rank == 0:
             print(json.dumps(out), flush=True)
