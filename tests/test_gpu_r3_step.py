@@ -256,9 +256,10 @@ def test_coset_ntt_with_merged_tables_equals_separate_tables_and_oracle(gpu_ctx,
     del outs, x, y; gpu_ctx.trim()
 
 
-@pytest.mark.parametrize("nodes,arity,last", [(1, 16, 16), (1, 16, 3), (37, 16, 16), (512, 16, 11), (257, 16, 16), (513, 16, 16), (200, 9, 2), (64, 12, 12)])
+@pytest.mark.parametrize("nodes,arity,last", [(1, 16, 16), (1, 16, 3), (37, 16, 16), (512, 16, 11), (256, 16, 7), (257, 16, 16), (513, 16, 16), (200, 9, 2), (64, 12, 12), (4096, 16, 5), (4097, 16, 16)])
 def test_small_merkle_levels_five_wave_kernel_equals_oracle_and_one_wave_kernel(gpu_ctx, oracle, nodes, arity, last):
-    """Merkle levels of up to 256 nodes run one node per five-wave workgroup (poseidon_chain.hpp k_hash_ds_chain; above that one wave per node):
+    """Merkle levels of up to 256 nodes run one node per five-wave workgroup (poseidon_chain.hpp k_hash_ds_chain), up to 4096 one wave per node, above that
+    the wave-pair kernel:
     the oracle's hash_with_ds_dynamic on every node (ragged last node, one- and two-permutation inputs), and the one-wave kernel under option
     "sponge_one_wave" on all of them."""
     import numpy as np
@@ -278,9 +279,9 @@ def test_small_merkle_levels_five_wave_kernel_equals_oracle_and_one_wave_kernel(
         gpu_ctx._chk(gpu_ctx.lib.stark_ctx_set_option(gpu_ctx.h, b"sponge_one_wave", 0))
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (300, 4), (2048, 16), (2049, 16), (8192, 16), (8193, 8)])
+@pytest.mark.parametrize("n,m", [(1, 1), (300, 4), (2048, 16), (2049, 16), (4096, 16), (4097, 2), (8192, 16), (8193, 8)])
 def test_small_leaf_layers_five_wave_kernel_equals_oracle(gpu_ctx, oracle, n, m):
-    """hash_leaf_pair over layers of up to 2048 leaves: one leaf per five-wave workgroup (k_leaf_pair_chain), up to 8192 one wave per leaf (k_leaf_pair_coop),
+    """hash_leaf_pair over layers of up to 2048 leaves: one leaf per five-wave workgroup (k_leaf_pair_chain), up to 4096 one wave per leaf (k_leaf_pair_coop),
     above that the wave-pair kernel; oracle on every leaf, with and without f_next."""
     f = oracle.synth_column(700 + n, 0, 0, n); fn = oracle.synth_column(700 + n, 1, 0, (n + m - 1) // m)
     assert (gpu_ctx.leaf_pair_hash(f, fn, m) == oracle.leaf_pair_hash(f, fn, m)).all()
